@@ -1,0 +1,145 @@
+/* kokoro_hip.h -- C ABI of the MI355X-native Kokoro-82M acoustic path (libkokoro_hip.so).
+ *
+ * The reference (stevenmiller888/mlx-audio) has no FFI: its hot path sits behind plain Python
+ * callables that dispatch every op to the MLX runtime.  This header is the boundary a maintainer
+ * would bind instead (ctypes stub in INTEGRATION.md).  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; kk_last_error() gives the message.
+ *     No C++ exception crosses this boundary.
+ *   - all data pointers are DEVICE pointers (hipMalloc / torch.cuda tensors) unless the parameter is
+ *     documented as host memory.  The caller owns every buffer; the library never frees or keeps one
+ *     beyond the call, except the weights it copied in kk_load_tensor/kk_finalize.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous; no entry
+ *     point synchronises the device except kk_finalize.
+ *   - a kk_model is immutable after kk_finalize and may be shared by threads that use distinct
+ *     streams and workspaces (the debug hooks at the end are NOT thread safe).
+ *   - tensors are "frames-major": [B][L][C] with C contiguous.
+ */
+#ifndef KOKORO_HIP_H
+#define KOKORO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KK_ABI_VERSION 1
+
+enum { KK_DTYPE_F32 = 0, KK_DTYPE_BF16 = 1, KK_DTYPE_I32 = 2, KK_DTYPE_F16 = 3 };
+enum { KK_NOISE_ZERO = 0, KK_NOISE_INJECTED = 1, KK_NOISE_PHILOX = 2 };
+
+typedef struct kk_model kk_model;
+
+/* Hyper-parameters: mlx_audio/tts/models/kokoro/kokoro.py:47-63 (ModelConfig), values pinned by
+ * mlx_audio/tts/tests/test_models.py:92-122; Albert defaults mlx_audio/tts/models/kokoro/modules.py:418-435. */
+typedef struct kk_config {
+  int32_t n_token, hidden_dim, style_dim, n_layer, max_dur, text_encoder_kernel_size;
+  int32_t plbert_hidden, plbert_heads, plbert_intermediate, plbert_max_pos, plbert_layers, plbert_embedding;
+  int32_t decoder_hidden;             /* 1024, hard-coded at istftnet.py:917-932 */
+  int32_t upsample_initial_channel;
+  int32_t n_upsamples;                /* 2 */
+  int32_t upsample_rates[4];          /* 10, 6 */
+  int32_t upsample_kernel_sizes[4];   /* 20, 12 */
+  int32_t n_resblock_kernels;         /* 3 */
+  int32_t resblock_kernel_sizes[4];   /* 3, 7, 11 */
+  int32_t resblock_dilations[4][3];   /* {1,3,5} x3 */
+  int32_t gen_istft_n_fft, gen_istft_hop_size; /* 20, 5 */
+  int32_t compute_dtype;              /* KK_DTYPE_F32 (exact path) or KK_DTYPE_BF16 (MFMA path) */
+} kk_config;
+
+/* Model(config)  --  kokoro.py:83-113 */
+int kk_create(const kk_config* cfg, kk_model** out);
+void kk_destroy(kk_model* m);
+
+/* model.load_weights(...) after Model.sanitize  --  mlx_audio/tts/utils.py:217-262, kokoro.py:172-252,
+ * istftnet.py:965-979.  `name` is the MLX-side parameter name; `data` is HOST memory in `dtype`
+ * (F32 / BF16 / F16).  Conv weights may arrive in either layout ([O,K,I] MLX or [O,I,K] PyTorch): the
+ * library decides by the expected shape, not by the reference's check_array_shape heuristic
+ * (mlx_audio/tts/models/base.py:21-34).  PyTorch-side LSTM / gamma / beta names are accepted too. */
+int kk_load_tensor(kk_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* host_data);
+
+/* Folds weight_norm once (istftnet.py:53-93,130: g*v/(||v||+1e-7), recomputed per call in the
+ * reference), packs every matrix for the kernels and uploads.  Fails if a parameter is missing.
+ * Synchronises `stream`. */
+int kk_finalize(kk_model* m, void* stream);
+
+/* Bytes of scratch kk_forward* needs for a batch of B utterances of at most Tmax tokens (BOS/EOS
+ * included) and Fmax frames (Fmax = 0: text stage only). */
+size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax);
+
+/* Text stage of Model.__call__  --  kokoro.py:135-150 and :159-161:
+ *   Albert -> bert_encoder -> DurationEncoder -> duration LSTM/proj -> pred_dur ; TextEncoder.
+ * ids      [B][Tmax] int32, zero padded, row b = [0, ids..., 0] (kokoro.py:135)
+ * lens     [B] int32, tokens per utterance including the two zeros
+ * ref_s    [B][256] float32 style rows (pipeline.py:236; [:128] decoder, [128:] prosody, kokoro.py:145,165)
+ * speed    [B] float32
+ * pred_dur_out [B][Tmax] int32  = clip(round(sum(sigmoid(.))/speed), 1) (kokoro.py:149-150), 0 past lens[b]
+ * The stage's results stay in `workspace` for kk_forward_audio. */
+int kk_forward_text(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+                    const float* speed, void* workspace, size_t workspace_bytes, int32_t* pred_dur_out);
+
+/* Audio stage of Model.__call__  --  kokoro.py:151-165: alignment, F0Ntrain, Decoder, Generator, iSTFT.
+ * dur       [B][Tmax] int32 durations to realise (pred_dur_out, or forced ones)
+ * Fmax      frame capacity per utterance; frames past it are dropped (nframes_out reports min(sum, Fmax))
+ * noise_mode / sine_noise / seed : the reference draws N(0,1) at istftnet.py:620; KK_NOISE_INJECTED reads
+ *           sine_noise [B][600*Fmax][9] float32, KK_NOISE_PHILOX generates it on the fly from `seed`.
+ * wav_out   [B][600*Fmax] float32 (zeros past 600*nframes)   -- Output.audio, kokoro.py:165-170
+ * nframes_out [B] int32 */
+int kk_forward_audio(kk_model* m, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur, int Fmax,
+                     int noise_mode, const float* sine_noise, uint64_t seed, void* workspace, size_t workspace_bytes, float* wav_out,
+                     int32_t* nframes_out);
+
+/* Model.__call__ in one call (kokoro.py:120-170) without the reference's mid-forward host sync
+ * (kokoro.py:151-153): durations are `forced_dur` if non-null, else the predicted ones, realised on
+ * device and truncated at Fmax frames. */
+int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s, const float* speed,
+               const int32_t* forced_dur, int Fmax, int noise_mode, const float* sine_noise, uint64_t seed, void* workspace,
+               size_t workspace_bytes, float* wav_out, int32_t* pred_dur_out, int32_t* nframes_out);
+
+const char* kk_last_error(void);
+int kk_abi_version(void);
+
+/* ---- single-kernel entry points (used by the parity tests; same kernels kk_forward launches) ---- */
+
+/* mx.conv1d / mx.conv_transpose1d / nn.Linear  --  istftnet.py:137-157.  w_packed [K][Cin][ldw] fp32 (device). */
+int kk_op_conv1d(void* stream, int B, const void* x, int ldx, int Lin_rows, const int32_t* lin, const float* w_packed, int ldw,
+                 const float* bias, int Cin, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift, float in_slope,
+                 int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out, int ldo, int Lout_rows,
+                 const int32_t* lout, int in_dtype, int out_dtype);
+/* InstanceNorm statistics + AdaIN1d + activation (+ pool)  --  istftnet.py:216-268,327-338,382,874-882 */
+int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta, int gbs,
+                int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out, int ldo, int Cpad,
+                int Lout_rows, float* scratch, size_t scratch_floats, int dtype, int fast);
+/* nn.LayerNorm / AdaLayerNorm  --  modules.py:33,71-90 */
+int kk_op_layernorm(void* stream, int B, const void* x, int ldx, const void* res, int ldr, int L_rows, const int32_t* len, int C,
+                    const float* w, const float* b, const float* gamma_beta, int gbs, float eps, int act, float slope, void* out, int ldo,
+                    int dtype);
+/* LSTM recurrence  --  modules.py:152-239 */
+int kk_op_lstm(void* stream, int B, const float* xproj, const float* whT, int H, int L_rows, const int32_t* len, void* out, int ldo,
+               int dtype);
+/* AlbertSelfAttention core  --  modules.py:497-512 */
+int kk_op_attention(void* stream, int B, const void* qkv, int ld, int T_rows, const int32_t* len, int heads, void* out, int ldo, int dtype);
+/* SourceModuleHnNSF + MLXSTFT.transform  --  istftnet.py:606-680,463-495 */
+int kk_op_source_stft(void* stream, int B, const float* f0, int L2_rows, const int32_t* len2, const float* lin_w9, float lin_b,
+                      int noise_mode, const float* noise, uint64_t seed, float* phase_scratch, float* har_source, void* har, int ldhar,
+                      int dtype);
+/* exp/sin + MLXSTFT.inverse + istft  --  istftnet.py:804-806,497-523; mlx_audio/utils.py:104-158 */
+int kk_op_istft_head(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, float* wav, int dtype, int fast);
+
+/* ---- debug hooks (tests only; not thread safe) ----
+ * Named intermediates of the last kk_forward*: "bert_dur" "d" "t_en" "en" "asr" "F0_pred" "N_pred" "dec_out"
+ * "har_source" "har" "gen_pre_res0" "gen_stage0" "gen_pre_res1" "gen_stage1" "conv_post".
+ * Data format: dense float32 [B][rows][C] on the device. */
+int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channels);
+int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
+int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
+void kk_debug_clear(kk_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOKORO_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libkokoro_hip.so (include/kokoro_hip.h).  Fails loudly when the library
+is missing: there is no CPU or PyTorch fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkokoro_hip.so")
+
+KK_F32, KK_BF16, KK_I32, KK_F16 = 0, 1, 2, 3
+NOISE_ZERO, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_GELU, ACT_SNAKE = 0, 1, 2, 3
+
+
+class KKConfig(C.Structure):
+    _fields_ = [
+        ("n_token", C.c_int32), ("hidden_dim", C.c_int32), ("style_dim", C.c_int32), ("n_layer", C.c_int32),
+        ("max_dur", C.c_int32), ("text_encoder_kernel_size", C.c_int32),
+        ("plbert_hidden", C.c_int32), ("plbert_heads", C.c_int32), ("plbert_intermediate", C.c_int32),
+        ("plbert_max_pos", C.c_int32), ("plbert_layers", C.c_int32), ("plbert_embedding", C.c_int32),
+        ("decoder_hidden", C.c_int32), ("upsample_initial_channel", C.c_int32), ("n_upsamples", C.c_int32),
+        ("upsample_rates", C.c_int32 * 4), ("upsample_kernel_sizes", C.c_int32 * 4),
+        ("n_resblock_kernels", C.c_int32), ("resblock_kernel_sizes", C.c_int32 * 4),
+        ("resblock_dilations", (C.c_int32 * 3) * 4),
+        ("gen_istft_n_fft", C.c_int32), ("gen_istft_hop_size", C.c_int32), ("compute_dtype", C.c_int32),
+    ]
+
+
+# every symbol include/kokoro_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+SIGNATURES = {
+    "kk_create": (_i, [C.POINTER(KKConfig), C.POINTER(_vp)]),
+    "kk_destroy": (None, [_vp]),
+    "kk_load_tensor": (_i, [_vp, C.c_char_p, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "kk_finalize": (_i, [_vp, _vp]),
+    "kk_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "kk_forward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kk_forward_audio": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp, _sz, _vp, _vp]),
+    "kk_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp, _sz, _vp, _vp, _vp]),
+    "kk_last_error": (C.c_char_p, []),
+    "kk_abi_version": (_i, []),
+    "kk_op_conv1d": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _f, _i, _vp, _i, _i, _vp, _i, _i]),
+    "kk_op_adain": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _i]),
+    "kk_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _f, _vp, _i, _i]),
+    "kk_op_lstm": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "kk_op_attention": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
+    "kk_op_source_stft": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _vp, _i, _i]),
+    "kk_op_istft_head": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "kk_debug_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "kk_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
+    "kk_debug_override": (_i, [_vp, C.c_char_p, _vp]),
+    "kk_debug_clear": (None, [_vp]),
+}
+
+_lib = None
+
+
+class KokoroHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises KokoroHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KokoroHipError(
+            f"{LIB_PATH} not found: build it with `python mlx-audio_amd/build.py` (hipcc, gfx950). "
+            "The Kokoro hot path has no CPU or PyTorch fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kk_abi_version() != 1:
+        raise KokoroHipError("libkokoro_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().kk_last_error()
+        raise KokoroHipError(f"{what}: {msg.decode() if msg else 'unknown error'}")

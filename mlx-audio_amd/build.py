@@ -1,0 +1,68 @@
+"""Build libkokoro_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Usage:  python mlx-audio_amd/build.py [--force]
+The shared object lands next to this file so it travels with the repository snapshot to the
+GPU box (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libkokoro_hip.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p) and f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "kokoro_hip.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    stamp = os.path.join(OBJ, "digest.txt")
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(OBJ, src[:-4] + ".o")
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, _sources()))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {OUT}")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

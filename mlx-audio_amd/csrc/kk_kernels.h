@@ -1,0 +1,164 @@
+// Launch wrappers of every device kernel (host-callable, enqueue on the given stream, never sync).
+#pragma once
+#include "kk_common.h"
+
+// ---- convolution family (kk_conv.hip, kk_conv_mfma.hip)
+int kk_launch_conv_generic(const KKConvArgs& a, int B, int in_dtype, int out_dtype, hipStream_t st);
+
+// ---- normalisation family (kk_norm.hip)
+struct KKStatsArgs {
+  const void* x;
+  long long xbs;
+  int ldx;
+  int C;
+  int Lmax;
+  KKLen len;
+  float* partial;  // scratch: kk_stats_partial_floats()
+  int nchunk;      // filled by the launcher
+  int rows_per_chunk;
+  float* mean;  // [B][C]
+  float* rstd;  // [B][C]
+  float eps;
+};
+size_t kk_stats_partial_floats(int B, int C, int Lmax, int rows_per_chunk);
+int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st);
+
+struct KKAdainArgs {
+  const void* x;
+  long long xbs;
+  int ldx;
+  void* out;
+  long long obs;
+  int ldo;
+  int C, Cpad;   // channels computed / channels written (pad channels are zero-filled)
+  int Lmax_out;  // rows of the output buffer to cover
+  KKLen len_in;  // valid input rows; valid output rows = pool ? 2*Lin : Lin
+  const float* mean;
+  const float* rstd;  // [B][C]
+  const float* gb;    // style projection: gamma = gb[b*gbs + c], beta = gb[b*gbs + C + c]
+  int gbs;
+  int act;  // KK_ACT_NONE / LRELU / SNAKE
+  float slope;
+  const float* alpha;  // [C], Snake
+  int pool;            // 1: depth-wise convT k3 s2 p1 + front pad after the activation
+  const float* pool_w; // [C][3] (weight-norm folded)
+  const float* pool_b; // [C]
+  int fast;            // 1: hardware sin approximation (bf16 mode)
+};
+int kk_launch_adain_act(const KKAdainArgs& a, int B, int dtype, hipStream_t st);
+
+struct KKLnArgs {
+  const void* x;
+  long long xbs;
+  int ldx;
+  const void* res;  // optional: LN(x + res)
+  long long rbs;
+  int ldr;
+  void* out;
+  long long obs;
+  int ldo;
+  int C;
+  int Lmax;
+  KKLen len;
+  const float* w;
+  const float* bias;  // affine (when gb == null)
+  const float* gb;    // AdaLayerNorm: (1 + gamma) * xhat + beta
+  int gbs;
+  float eps;
+  int act;
+  float slope;
+};
+int kk_launch_layernorm(const KKLnArgs& a, int B, int dtype, hipStream_t st);
+
+// ---- bidirectional LSTM recurrence (kk_lstm.hip)
+struct KKLstmArgs {
+  const float* xproj;  // [B][Lmax][2][4H] : x @ Wx^T + (b_ih + b_hh), gate order i,f,g,o
+  const float* whT;    // [2][H][4H]       : Wh transposed per direction
+  void* out;           // [B][Lmax][ldo], forward at channel 0, backward at channel H
+  long long obs;
+  int ldo;
+  int H;
+  int Lmax;
+  KKLen len;
+};
+int kk_launch_lstm(const KKLstmArgs& a, int B, int dtype, hipStream_t st);
+
+// ---- Albert pieces (kk_albert.hip)
+struct KKEmbedArgs {
+  const int* ids;  // [B][Tmax]
+  const float* word;
+  const float* pos;
+  const float* type;  // embedding tables [*][E]
+  const float* ln_w;
+  const float* ln_b;
+  void* out;  // [B][Tmax][ldo]
+  long long obs;
+  int ldo;
+  int E;
+  int Tmax;
+  KKLen len;
+  float eps;
+};
+int kk_launch_albert_embed(const KKEmbedArgs& a, int B, int dtype, hipStream_t st);
+
+struct KKAttnArgs {
+  const void* qkv;  // [B][Tmax][ld]: q at h*64, k at hs + h*64, v at 2*hs + h*64
+  long long bs;
+  int ld;
+  void* out;  // [B][Tmax][ldo] context at h*64
+  long long obs;
+  int ldo;
+  int heads, hs;
+  int Tmax;
+  KKLen len;
+  float scale;  // 1/sqrt(64)
+};
+int kk_launch_attention(const KKAttnArgs& a, int B, int dtype, hipStream_t st);
+
+// ---- misc (kk_misc.hip)
+// out[b][o] = sum_j wT[j][o] * s[b][soff + j] + bias[o]   (all style projections of one style half at once)
+int kk_launch_style_fc(const float* ref_s, int soff, const float* wT, const float* bias, float* out, int N, int B, hipStream_t st);
+// cat[b][t][coff + j] = s[b][soff + j] for t < len[b], else 0
+int kk_launch_fill_style(const float* ref_s, int soff, void* out, long long obs, int ldo, int coff, int S, int Lmax, KKLen len, int B,
+                         int dtype, hipStream_t st);
+// out[b][t][c] = table[ids[b][t]][c]  (TextEncoder embedding, modules.py:42)
+int kk_launch_embedding(const int* ids, const float* table, void* out, long long obs, int ldo, int C, int Tmax, KKLen len, int B,
+                        int dtype, hipStream_t st);
+// duration head (kokoro.py:148-150): dur[b][t] = max(1, rint(sum_o sigmoid(x.W[o] + bias[o]) / speed[b])), raw sum kept in dur_f
+int kk_launch_duration(const void* x, long long xbs, int ldx, const float* W, const float* bias, int Cin, int nout, const float* speed,
+                       int* dur, float* dur_f, int Tmax, KKLen len, int B, int dtype, hipStream_t st);
+// alignment (kokoro.py:151-156): frame_idx[b][f] = token index of frame f, lenF[b] = min(sum dur, Fmax)
+int kk_launch_alignment(const int* dur, int Tmax, const int* lenT, int* frame_idx, int* lenF, int Fmax, int B, hipStream_t st);
+// length regulation (kokoro.py:157,162): out[b][f][coff + c] = in[b][frame_idx[b][f]][c]
+int kk_launch_gather_rows(const void* in, long long ibs, int ldi, const int* frame_idx, int Fmax, const int* lenF, void* out,
+                          long long obs, int ldo, int coff, int C, int B, int dtype, hipStream_t st);
+// strided channel-slice copy: out[b][l][coff + c] = in[b][l][c] (zero past len)
+int kk_launch_copy_slice(const void* in, long long ibs, int ldi, void* out, long long obs, int ldo, int coff, int C, int Lmax, KKLen len,
+                         int B, int dtype, hipStream_t st);
+int kk_launch_lens(const int* lenF, int* lens_out /*[4][B]: 2F, 20F, 120F+1, 600F*/, int B, int up0, int up1, int hop, hipStream_t st);
+
+// ---- harmonic source + STFT + iSTFT head (kk_source.hip)
+struct KKSourceArgs {
+  const float* f0;  // [B][L2max] predicted F0 curve (2 frames per 25 ms frame)
+  int L2max;
+  const int* len2;  // valid entries per utterance (2F)
+  float* phase;     // scratch [B][9][L2max]: 300 * 2*pi*cumsum(rad)
+  const float* lin_w;  // [9]
+  float lin_b;
+  const float* noise;  // optional injected N(0,1) [B][Nmax][9]; null -> Philox (seed) or zero
+  unsigned long long seed;
+  int noise_mode;  // 0 zero, 1 injected, 2 philox
+  float* har_source;  // [B][Nmax]
+  int Nmax;           // 300 * L2max
+  int upsample;       // 300
+};
+int kk_launch_source(const KKSourceArgs& a, int B, hipStream_t st);
+// har[b][t][0..10] = |STFT|, [11..21] = angle  (n_fft 20, hop 5, symmetric Hann, reflect pad; istftnet.py:463-495)
+int kk_launch_stft20(const float* har_source, int Nmax, const int* lenN, void* har, long long obs, int ldo, int Tfmax, int B, int dtype,
+                     hipStream_t st);
+// iSTFT head (istftnet.py:804-806,497-523; utils.py:104-158): x[b][t][22] -> wav[b][5*(frames-1)]
+int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav, long long wbs, int B,
+                         int dtype, int fast, hipStream_t st);
+// dtype-converting strided copy (debug hooks)
+int kk_launch_convert(const void* src, int sdt, long long sbs, int lds, void* dst, int ddt, long long dbs, int ldd, int C, int rows, int B,
+                      hipStream_t st);

@@ -1,0 +1,1222 @@
+// Host side of libkokoro_hip.so: weight intake, weight-norm folding / packing, the forward
+// orchestration of kokoro.py:120-170 as a sequence of kernel launches on the caller's stream,
+// and the C ABI declared in include/kokoro_hip.h.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kokoro_hip.h"
+#include "kk_common.h"
+#include "kk_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+int kk_fail(const char* msg) {
+  g_err = msg ? msg : "unknown error";
+  return -1;
+}
+static int failf(const char* fmt, const std::string& a) {
+  char buf[512];
+  snprintf(buf, sizeof buf, fmt, a.c_str());
+  return kk_fail(buf);
+}
+extern "C" const char* kk_last_error(void) { return g_err.c_str(); }
+extern "C" int kk_abi_version(void) { return KK_ABI_VERSION; }
+
+#define KK_TRY(x)            \
+  do {                       \
+    int rc__ = (x);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// model structures
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostTensor {
+  std::vector<float> d;
+  std::vector<int64_t> shape;
+};
+
+struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
+  size_t w_off = 0, b_off = 0;
+  bool has_bias = false;
+  int Cin = 0, Cout = 0, Kw = 0, ldw = 0;
+  const float* w = nullptr;
+  const float* b = nullptr;
+};
+struct VecW {
+  size_t off = 0;
+  int n = 0;
+  const float* p = nullptr;
+};
+struct LstmW {
+  ConvW in;  // [1][I][8H], bias = b_ih + b_hh, columns dir*4H + gate row
+  VecW whT;  // [2][H][4H]
+  int H = 0;
+};
+struct AdainRef {
+  size_t off = 0;  // offset of gamma in the style vector of its half; beta at off + C
+  int C = 0;
+};
+struct ResBlk1d {  // AdainResBlk1d, istftnet.py:825-899
+  int Cin = 0, Cout = 0;
+  bool up = false, learned = false;
+  AdainRef n1, n2;
+  ConvW conv1, conv2, sc;
+  VecW pool_w, pool_b;
+};
+struct ResBlock1 {  // AdaINResBlock1, istftnet.py:341-396
+  int C = 0, k = 0;
+  int dil[3] = {1, 3, 5};
+  ConvW c1[3], c2[3];
+  AdainRef a1[3], a2[3];
+  VecW al1[3], al2[3];
+};
+
+struct DebugEntry {
+  void* p;
+  int ld;
+  long long bs;
+  int rows, C, dtype, B;
+};
+
+}  // namespace
+
+struct kk_model {
+  kk_config cfg;
+  std::map<std::string, HostTensor> host;
+  bool finalized = false;
+  std::vector<float> pack;  // host staging of all packed fp32 parameters
+  float* dev = nullptr;     // device copy of `pack`
+  int adt = KK_F32;         // activation dtype
+
+  // Albert
+  VecW emb_word, emb_pos, emb_type, emb_ln_w, emb_ln_b;
+  ConvW map_in, qkv, att_dense, ffn, ffn_out, bert_encoder;
+  VecW att_ln_w, att_ln_b, full_ln_w, full_ln_b;
+  // predictor
+  std::vector<LstmW> dur_lstms;
+  std::vector<AdainRef> dur_adaln;
+  LstmW pred_lstm, shared_lstm, text_lstm;
+  VecW dur_W, dur_b;
+  ResBlk1d f0blk[3], nblk[3];
+  ConvW f0_proj, n_proj;
+  // text encoder
+  VecW te_emb;
+  std::vector<ConvW> te_cnn;
+  std::vector<VecW> te_ln_w, te_ln_b;
+  // decoder
+  ResBlk1d enc, dec[4];
+  ConvW f0_conv, n_conv, asr_res;
+  // generator
+  VecW lin_w;
+  float lin_b = 0.f;
+  ConvW noise_conv[4], ups[4], conv_post;
+  ResBlock1 noise_res[4];
+  std::vector<ResBlock1> resblocks;
+  // style projections (all AdaIN / AdaLN fc's), one matrix per style half
+  VecW sp_wT, sp_b, sd_wT, sd_b;  // prosody half (ref_s[128:]) / decoder half (ref_s[:128])
+  int Np = 0, Nd = 0;
+
+  std::map<std::string, DebugEntry> dbg;
+  std::map<std::string, const float*> dbg_over;
+};
+
+// ------------------------------------------------------------------------------------------------
+// create / load
+// ------------------------------------------------------------------------------------------------
+extern "C" int kk_create(const kk_config* cfg, kk_model** out) {
+  if (!cfg || !out) return kk_fail("kk_create: null argument");
+  if (cfg->n_upsamples != 2 || cfg->n_resblock_kernels < 1 || cfg->n_resblock_kernels > 4)
+    return kk_fail("kk_create: unsupported generator geometry");
+  if (cfg->plbert_hidden != cfg->plbert_heads * 64) return kk_fail("kk_create: Albert head size must be 64");
+  if (cfg->style_dim != 128) return kk_fail("kk_create: style_dim must be 128 (kokoro.py:145,165 split ref_s at 128)");
+  if (cfg->hidden_dim % 32 != 0 || cfg->hidden_dim / 2 > 256) return kk_fail("kk_create: hidden_dim must be a multiple of 32, <= 512");
+  if (cfg->gen_istft_n_fft != 20 || cfg->gen_istft_hop_size != 5) return kk_fail("kk_create: iSTFT head is built for n_fft 20 / hop 5");
+  if (cfg->compute_dtype != KK_DTYPE_F32 && cfg->compute_dtype != KK_DTYPE_BF16) return kk_fail("kk_create: compute_dtype");
+  kk_model* m = new (std::nothrow) kk_model();
+  if (!m) return kk_fail("kk_create: out of memory");
+  m->cfg = *cfg;
+  m->adt = cfg->compute_dtype == KK_DTYPE_BF16 ? KK_BF16 : KK_F32;
+  *out = m;
+  return 0;
+}
+
+extern "C" void kk_destroy(kk_model* m) {
+  if (!m) return;
+  if (m->dev) (void)hipFree(m->dev);
+  delete m;
+}
+
+static float bf16_to_f32(uint16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static float f16_to_f32(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, f = h & 1023;
+  uint32_t u;
+  if (e == 0) {
+    if (f == 0) u = s << 31;
+    else {
+      int ee = -1;
+      uint32_t ff = f;
+      while (!(ff & 1024)) { ff <<= 1; ++ee; }
+      u = (s << 31) | ((uint32_t)(127 - 15 - ee) << 23) | ((ff & 1023) << 13);
+    }
+  } else if (e == 31) u = (s << 31) | 0x7F800000u | (f << 13);
+  else u = (s << 31) | ((e - 15 + 127) << 23) | (f << 13);
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+
+static std::string normalise_name(const std::string& in) {
+  // PyTorch-side names -> MLX-side names (kokoro.py:24-44, 189-196)
+  static const std::pair<const char*, const char*> lstm_map[] = {
+      {"weight_ih_l0_reverse", "Wx_backward"}, {"weight_hh_l0_reverse", "Wh_backward"}, {"bias_ih_l0_reverse", "bias_ih_backward"},
+      {"bias_hh_l0_reverse", "bias_hh_backward"}, {"weight_ih_l0", "Wx_forward"},       {"weight_hh_l0", "Wh_forward"},
+      {"bias_ih_l0", "bias_ih_forward"},          {"bias_hh_l0", "bias_hh_forward"}};
+  const size_t dot = in.rfind('.');
+  if (dot == std::string::npos) return in;
+  const std::string base = in.substr(0, dot), leaf = in.substr(dot + 1);
+  for (auto& kv : lstm_map)
+    if (leaf == kv.first) return base + "." + kv.second;
+  if (in.rfind("text_encoder.", 0) == 0) {
+    if (leaf == "gamma") return base + ".weight";
+    if (leaf == "beta") return base + ".bias";
+  }
+  return in;
+}
+
+extern "C" int kk_load_tensor(kk_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* data) {
+  if (!m || !name || !data || ndim < 0 || ndim > 4) return kk_fail("kk_load_tensor: bad argument");
+  if (m->finalized) return kk_fail("kk_load_tensor: model already finalized");
+  std::string nm = normalise_name(name);
+  if (nm.find("position_ids") != std::string::npos) return 0;  // dropped by sanitize (kokoro.py:177-179)
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return kk_fail("kk_load_tensor: bad shape");
+    t.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  t.d.resize(n);
+  if (dtype == KK_DTYPE_F32) memcpy(t.d.data(), data, n * 4);
+  else if (dtype == KK_DTYPE_BF16) for (size_t i = 0; i < n; ++i) t.d[i] = bf16_to_f32(((const uint16_t*)data)[i]);
+  else if (dtype == KK_DTYPE_F16) for (size_t i = 0; i < n; ++i) t.d[i] = f16_to_f32(((const uint16_t*)data)[i]);
+  else return kk_fail("kk_load_tensor: dtype must be F32, BF16 or F16");
+  m->host[nm] = std::move(t);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: fold weight-norm, pack, upload
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Packer {
+  kk_model* m;
+  std::string err;
+  bool ok() const { return err.empty(); }
+  size_t alloc(size_t n) {
+    size_t off = (m->pack.size() + 63) & ~(size_t)63;  // 256-byte alignment
+    m->pack.resize(off + n, 0.f);
+    return off;
+  }
+  const HostTensor* get(const std::string& name) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) {
+      if (err.empty()) err = "missing parameter: " + name;
+      return nullptr;
+    }
+    return &it->second;
+  }
+  // 3-D conv weight in MLX layout [A][K][C]; accepts the PyTorch layout [A][C][K] as well.
+  bool conv3(const std::string& name, int A, int K, int C, std::vector<float>& out) {
+    const HostTensor* t = get(name);
+    if (!t) return false;
+    out.assign((size_t)A * K * C, 0.f);
+    if (t->shape.size() == 3 && t->shape[0] == A && t->shape[1] == K && t->shape[2] == C) {
+      out = t->d;
+      return true;
+    }
+    if (t->shape.size() == 3 && t->shape[0] == A && t->shape[1] == C && t->shape[2] == K) {
+      for (int a = 0; a < A; ++a)
+        for (int c = 0; c < C; ++c)
+          for (int k = 0; k < K; ++k) out[((size_t)a * K + k) * C + c] = t->d[((size_t)a * C + c) * K + k];
+      return true;
+    }
+    if (err.empty()) err = "unexpected shape for " + name;
+    return false;
+  }
+  bool vec(const std::string& name, size_t n, std::vector<float>& out) {
+    const HostTensor* t = get(name);
+    if (!t) return false;
+    if (t->d.size() != n) {
+      if (err.empty()) err = "unexpected size for " + name;
+      return false;
+    }
+    out = t->d;
+    return true;
+  }
+  VecW put(const std::vector<float>& v) {
+    VecW r;
+    r.n = (int)v.size();
+    r.off = alloc(v.size());
+    memcpy(&m->pack[r.off], v.data(), v.size() * 4);
+    return r;
+  }
+  VecW put_named(const std::string& name, size_t n) {
+    std::vector<float> v;
+    if (!vec(name, n, v)) return VecW();
+    return put(v);
+  }
+  // weight_norm (istftnet.py:53-93 with dim=0): per leading index a, w = g[a] * v[a] / (||v[a]||_2 + 1e-7)
+  bool folded(const std::string& prefix, int A, int K, int C, std::vector<float>& w) {
+    std::vector<float> g;
+    if (!conv3(prefix + ".weight_v", A, K, C, w)) return false;
+    if (!vec(prefix + ".weight_g", (size_t)A, g)) return false;
+    for (int a = 0; a < A; ++a) {
+      float ss = 0.f;
+      float* row = &w[(size_t)a * K * C];
+      for (int i = 0; i < K * C; ++i) ss += row[i] * row[i];
+      const float nrm = sqrtf(ss) + 1e-7f;
+      for (int i = 0; i < K * C; ++i) row[i] = row[i] / nrm * g[a];
+    }
+    return true;
+  }
+  // pack a conv weight given as wsrc[o][k][i] into [k][i][ldw]
+  ConvW pack_oki(const std::vector<float>& wsrc, int O, int K, int I, const std::vector<float>* bias) {
+    ConvW c;
+    c.Cin = I; c.Cout = O; c.Kw = K; c.ldw = kk_cdiv(O, 64) * 64;
+    c.w_off = alloc((size_t)K * I * c.ldw);
+    float* dst = &m->pack[c.w_off];
+    for (int o = 0; o < O; ++o)
+      for (int k = 0; k < K; ++k)
+        for (int i = 0; i < I; ++i) dst[((size_t)k * I + i) * c.ldw + o] = wsrc[((size_t)o * K + k) * I + i];
+    if (bias) {
+      c.has_bias = true;
+      c.b_off = alloc(O);
+      memcpy(&m->pack[c.b_off], bias->data(), (size_t)O * 4);
+    }
+    return c;
+  }
+  // ConvWeighted used as conv1d: weight_v [O][K][I]
+  ConvW convw(const std::string& prefix, int O, int K, int I, bool bias) {
+    std::vector<float> w, b;
+    if (!folded(prefix, O, K, I, w)) return ConvW();
+    if (bias && !vec(prefix + ".bias", (size_t)O, b)) return ConvW();
+    return pack_oki(w, O, K, I, bias ? &b : nullptr);
+  }
+  // ConvWeighted used as conv_transpose1d (Generator.ups, istftnet.py:725-734,161-166): weight_v [Cin][K][Cout], norm over
+  // each Cin slice, bias [Cout]
+  ConvW convw_t(const std::string& prefix, int Cin, int K, int Cout) {
+    std::vector<float> w, b;
+    if (!folded(prefix, Cin, K, Cout, w)) return ConvW();
+    if (!vec(prefix + ".bias", (size_t)Cout, b)) return ConvW();
+    ConvW c;
+    c.Cin = Cin; c.Cout = Cout; c.Kw = K; c.ldw = kk_cdiv(Cout, 64) * 64;
+    c.w_off = alloc((size_t)K * Cin * c.ldw);
+    float* dst = &m->pack[c.w_off];
+    for (int i = 0; i < Cin; ++i)
+      for (int k = 0; k < K; ++k)
+        for (int o = 0; o < Cout; ++o) dst[((size_t)k * Cin + i) * c.ldw + o] = w[((size_t)i * K + k) * Cout + o];
+    c.has_bias = true;
+    c.b_off = alloc(Cout);
+    memcpy(&m->pack[c.b_off], b.data(), (size_t)Cout * 4);
+    return c;
+  }
+  // nn.Conv1d: weight [O][K][I] (+ PyTorch [O][I][K]), bias [O]
+  ConvW conv_plain(const std::string& prefix, int O, int K, int I) {
+    std::vector<float> w, b;
+    if (!conv3(prefix + ".weight", O, K, I, w)) return ConvW();
+    if (!vec(prefix + ".bias", (size_t)O, b)) return ConvW();
+    return pack_oki(w, O, K, I, &b);
+  }
+  // nn.Linear: weight [O][I], bias [O]
+  ConvW linear(const std::string& prefix, int O, int I) {
+    std::vector<float> w, b;
+    if (!vec(prefix + ".weight", (size_t)O * I, w)) return ConvW();
+    if (!vec(prefix + ".bias", (size_t)O, b)) return ConvW();
+    return pack_oki(w, O, 1, I, &b);
+  }
+  LstmW lstm(const std::string& prefix, int I, int H) {
+    LstmW l;
+    l.H = H;
+    const int G = 4 * H;
+    std::vector<float> w((size_t)2 * G * I), b((size_t)2 * G), whT((size_t)2 * H * G);
+    const char* dirs[2] = {"forward", "backward"};
+    for (int d = 0; d < 2; ++d) {
+      std::vector<float> wx, wh, bi, bh;
+      if (!vec(prefix + ".Wx_" + dirs[d], (size_t)G * I, wx)) return l;
+      if (!vec(prefix + ".Wh_" + dirs[d], (size_t)G * H, wh)) return l;
+      if (!vec(prefix + ".bias_ih_" + dirs[d], (size_t)G, bi)) return l;
+      if (!vec(prefix + ".bias_hh_" + dirs[d], (size_t)G, bh)) return l;
+      memcpy(&w[(size_t)d * G * I], wx.data(), wx.size() * 4);
+      for (int g = 0; g < G; ++g) b[(size_t)d * G + g] = bi[g] + bh[g];  // mx.addmm(b_ih + b_hh, ...) modules.py:156-158
+      for (int g = 0; g < G; ++g)
+        for (int j = 0; j < H; ++j) whT[((size_t)d * H + j) * G + g] = wh[(size_t)g * H + j];
+    }
+    l.in = pack_oki(w, 2 * G, 1, I, &b);
+    l.whT = put(whT);
+    return l;
+  }
+};
+
+struct StyleBuilder {  // concatenates every `fc` of one style half into wT [128][N]
+  std::vector<std::pair<std::string, int>> items;  // (prefix, C) : fc.weight [2C][128]
+  AdainRef add(const std::string& prefix, int C) {
+    AdainRef r;
+    r.C = C;
+    size_t off = 0;
+    for (auto& it : items) off += 2 * (size_t)it.second;
+    r.off = off;
+    items.emplace_back(prefix, C);
+    return r;
+  }
+  bool build(Packer& P, VecW& wT, VecW& bias, int& N) {
+    size_t n = 0;
+    for (auto& it : items) n += 2 * (size_t)it.second;
+    N = (int)n;
+    std::vector<float> W((size_t)128 * n), Bv(n);
+    size_t off = 0;
+    for (auto& it : items) {
+      const int C2 = 2 * it.second;
+      std::vector<float> w, b;
+      if (!P.vec(it.first + ".fc.weight", (size_t)C2 * 128, w)) return false;
+      if (!P.vec(it.first + ".fc.bias", (size_t)C2, b)) return false;
+      for (int o = 0; o < C2; ++o) {
+        Bv[off + o] = b[o];
+        for (int j = 0; j < 128; ++j) W[(size_t)j * n + off + o] = w[(size_t)o * 128 + j];
+      }
+      off += C2;
+    }
+    wT = P.put(W);
+    bias = P.put(Bv);
+    return true;
+  }
+};
+
+ResBlk1d build_resblk1d(Packer& P, StyleBuilder& S, const std::string& p, int Cin, int Cout, bool up) {
+  ResBlk1d r;
+  r.Cin = Cin; r.Cout = Cout; r.up = up; r.learned = Cin != Cout;
+  r.n1 = S.add(p + ".norm1", Cin);
+  r.n2 = S.add(p + ".norm2", Cout);
+  r.conv1 = P.convw(p + ".conv1", Cout, 3, Cin, true);
+  r.conv2 = P.convw(p + ".conv2", Cout, 3, Cout, true);
+  if (r.learned) r.sc = P.convw(p + ".conv1x1", Cout, 1, Cin, false);
+  if (up) {
+    std::vector<float> w, b;
+    if (P.folded(p + ".pool", Cin, 3, 1, w) && P.vec(p + ".pool.bias", (size_t)Cin, b)) {
+      r.pool_w = P.put(w);  // [C][3]
+      r.pool_b = P.put(b);
+    }
+  }
+  return r;
+}
+
+ResBlock1 build_resblock1(Packer& P, StyleBuilder& S, const std::string& p, int C, int k, const int* dil) {
+  ResBlock1 r;
+  r.C = C; r.k = k;
+  for (int j = 0; j < 3; ++j) {
+    r.dil[j] = dil[j];
+    const std::string js = std::to_string(j);
+    r.c1[j] = P.convw(p + ".convs1." + js, C, k, C, true);
+    r.c2[j] = P.convw(p + ".convs2." + js, C, k, C, true);
+    r.a1[j] = S.add(p + ".adain1." + js, C);
+    r.a2[j] = S.add(p + ".adain2." + js, C);
+    r.al1[j] = P.put_named(p + ".alpha1." + js, (size_t)C);
+    r.al2[j] = P.put_named(p + ".alpha2." + js, (size_t)C);
+  }
+  return r;
+}
+
+void resolve(kk_model* m, ConvW& c) {
+  c.w = m->dev + c.w_off;
+  c.b = c.has_bias ? m->dev + c.b_off : nullptr;
+}
+void resolve(kk_model* m, VecW& v) { v.p = v.n ? m->dev + v.off : nullptr; }
+void resolve(kk_model* m, LstmW& l) { resolve(m, l.in); resolve(m, l.whT); }
+void resolve(kk_model* m, ResBlk1d& r) {
+  resolve(m, r.conv1); resolve(m, r.conv2);
+  if (r.learned) resolve(m, r.sc);
+  resolve(m, r.pool_w); resolve(m, r.pool_b);
+}
+void resolve(kk_model* m, ResBlock1& r) {
+  for (int j = 0; j < 3; ++j) {
+    resolve(m, r.c1[j]); resolve(m, r.c2[j]); resolve(m, r.al1[j]); resolve(m, r.al2[j]);
+  }
+}
+
+}  // namespace
+
+extern "C" int kk_finalize(kk_model* m, void* stream) {
+  if (!m) return kk_fail("kk_finalize: null model");
+  if (m->finalized) return 0;
+  const kk_config& c = m->cfg;
+  Packer P{m, ""};
+  StyleBuilder SP, SD;
+  const int H = c.hidden_dim, S = c.style_dim, hs = c.plbert_hidden, E = c.plbert_embedding, DH = c.decoder_hidden;
+  // ---- Albert (modules.py:438-649)
+  m->emb_word = P.put_named("bert.embeddings.word_embeddings.weight", (size_t)c.n_token * E);
+  m->emb_pos = P.put_named("bert.embeddings.position_embeddings.weight", (size_t)c.plbert_max_pos * E);
+  m->emb_type = P.put_named("bert.embeddings.token_type_embeddings.weight", (size_t)2 * E);
+  m->emb_ln_w = P.put_named("bert.embeddings.LayerNorm.weight", E);
+  m->emb_ln_b = P.put_named("bert.embeddings.LayerNorm.bias", E);
+  m->map_in = P.linear("bert.encoder.embedding_hidden_mapping_in", hs, E);
+  const std::string lp = "bert.encoder.albert_layer_groups.0.albert_layers.0.";
+  {
+    std::vector<float> w((size_t)3 * hs * hs), b((size_t)3 * hs);
+    const char* nm[3] = {"query", "key", "value"};
+    for (int i = 0; i < 3; ++i) {
+      std::vector<float> wi, bi;
+      if (P.vec(lp + "attention." + nm[i] + ".weight", (size_t)hs * hs, wi) && P.vec(lp + "attention." + nm[i] + ".bias", hs, bi)) {
+        memcpy(&w[(size_t)i * hs * hs], wi.data(), wi.size() * 4);
+        memcpy(&b[(size_t)i * hs], bi.data(), bi.size() * 4);
+      }
+    }
+    m->qkv = P.pack_oki(w, 3 * hs, 1, hs, &b);
+  }
+  m->att_dense = P.linear(lp + "attention.dense", hs, hs);
+  m->att_ln_w = P.put_named(lp + "attention.LayerNorm.weight", hs);
+  m->att_ln_b = P.put_named(lp + "attention.LayerNorm.bias", hs);
+  m->full_ln_w = P.put_named(lp + "full_layer_layer_norm.weight", hs);
+  m->full_ln_b = P.put_named(lp + "full_layer_layer_norm.bias", hs);
+  m->ffn = P.linear(lp + "ffn", c.plbert_intermediate, hs);
+  m->ffn_out = P.linear(lp + "ffn_output", hs, c.plbert_intermediate);
+  m->bert_encoder = P.linear("bert_encoder", H, hs);
+  // ---- prosody predictor (modules.py:288-342,380-387)
+  for (int i = 0; i < c.n_layer; ++i) {
+    m->dur_lstms.push_back(P.lstm("predictor.text_encoder.lstms." + std::to_string(2 * i), H + S, H / 2));
+    m->dur_adaln.push_back(SP.add("predictor.text_encoder.lstms." + std::to_string(2 * i + 1), H));
+  }
+  m->pred_lstm = P.lstm("predictor.lstm", H + S, H / 2);
+  m->shared_lstm = P.lstm("predictor.shared", H + S, H / 2);
+  m->dur_W = P.put_named("predictor.duration_proj.linear_layer.weight", (size_t)c.max_dur * H);
+  m->dur_b = P.put_named("predictor.duration_proj.linear_layer.bias", c.max_dur);
+  for (int which = 0; which < 2; ++which) {
+    const std::string nm = which == 0 ? "predictor.F0" : "predictor.N";
+    ResBlk1d* blk = which == 0 ? m->f0blk : m->nblk;
+    blk[0] = build_resblk1d(P, SP, nm + ".0", H, H, false);
+    blk[1] = build_resblk1d(P, SP, nm + ".1", H, H / 2, true);
+    blk[2] = build_resblk1d(P, SP, nm + ".2", H / 2, H / 2, false);
+    (which == 0 ? m->f0_proj : m->n_proj) = P.conv_plain(nm + "_proj", 1, 1, H / 2);
+  }
+  // ---- text encoder (modules.py:21-39)
+  m->te_emb = P.put_named("text_encoder.embedding.weight", (size_t)c.n_token * H);
+  for (int i = 0; i < c.n_layer; ++i) {
+    const std::string is = std::to_string(i);
+    m->te_cnn.push_back(P.convw("text_encoder.cnn." + is + ".0", H, c.text_encoder_kernel_size, H, true));
+    m->te_ln_w.push_back(P.put_named("text_encoder.cnn." + is + ".1.weight", H));
+    m->te_ln_b.push_back(P.put_named("text_encoder.cnn." + is + ".1.bias", H));
+  }
+  m->text_lstm = P.lstm("text_encoder.lstm", H, H / 2);
+  // ---- decoder (istftnet.py:902-945)
+  m->enc = build_resblk1d(P, SD, "decoder.encode", H + 2, DH, false);
+  for (int i = 0; i < 3; ++i) m->dec[i] = build_resblk1d(P, SD, "decoder.decode." + std::to_string(i), DH + 2 + 64, DH, false);
+  m->dec[3] = build_resblk1d(P, SD, "decoder.decode.3", DH + 2 + 64, H, true);
+  m->f0_conv = P.convw("decoder.F0_conv", 1, 3, 1, true);
+  m->n_conv = P.convw("decoder.N_conv", 1, 3, 1, true);
+  m->asr_res = P.convw("decoder.asr_res.0", 64, 1, H, true);
+  // ---- generator (istftnet.py:696-767)
+  const std::string g = "decoder.generator.";
+  {
+    std::vector<float> lw, lb;
+    if (P.vec(g + "m_source.l_linear.weight", 9, lw) && P.vec(g + "m_source.l_linear.bias", 1, lb)) {
+      m->lin_w = P.put(lw);
+      m->lin_b = lb[0];
+    }
+  }
+  const int C0 = c.upsample_initial_channel, nk = c.n_resblock_kernels;
+  const int d135[3] = {1, 3, 5};
+  for (int i = 0; i < c.n_upsamples; ++i) {
+    const int cin = C0 >> i, cout = C0 >> (i + 1);
+    const std::string is = std::to_string(i);
+    m->ups[i] = P.convw_t(g + "ups." + is, cin, c.upsample_kernel_sizes[i], cout);
+    if (i + 1 < c.n_upsamples) {
+      int sf0 = 1;
+      for (int j = i + 1; j < c.n_upsamples; ++j) sf0 *= c.upsample_rates[j];
+      m->noise_conv[i] = P.conv_plain(g + "noise_convs." + is, cout, sf0 * 2, c.gen_istft_n_fft + 2);
+      m->noise_res[i] = build_resblock1(P, SD, g + "noise_res." + is, cout, 7, d135);
+    } else {
+      m->noise_conv[i] = P.conv_plain(g + "noise_convs." + is, cout, 1, c.gen_istft_n_fft + 2);
+      m->noise_res[i] = build_resblock1(P, SD, g + "noise_res." + is, cout, 11, d135);
+    }
+    for (int j = 0; j < nk; ++j)
+      m->resblocks.push_back(
+          build_resblock1(P, SD, g + "resblocks." + std::to_string(i * nk + j), cout, c.resblock_kernel_sizes[j], c.resblock_dilations[j]));
+  }
+  m->conv_post = P.convw(g + "conv_post", c.gen_istft_n_fft + 2, 7, C0 >> c.n_upsamples, true);
+  if (P.ok()) {
+    SP.build(P, m->sp_wT, m->sp_b, m->Np);
+    SD.build(P, m->sd_wT, m->sd_b, m->Nd);
+  }
+  if (!P.ok()) return failf("kk_finalize: %s", P.err);
+
+  // ---- upload and resolve device pointers
+  if (hipMalloc((void**)&m->dev, m->pack.size() * sizeof(float)) != hipSuccess) return kk_fail("kk_finalize: hipMalloc failed");
+  if (hipMemcpyAsync(m->dev, m->pack.data(), m->pack.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+    return kk_fail("kk_finalize: upload failed");
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_finalize: stream sync failed");
+  VecW* vecs[] = {&m->emb_word, &m->emb_pos, &m->emb_type, &m->emb_ln_w, &m->emb_ln_b, &m->att_ln_w, &m->att_ln_b, &m->full_ln_w,
+                  &m->full_ln_b, &m->dur_W, &m->dur_b, &m->te_emb, &m->lin_w, &m->sp_wT, &m->sp_b, &m->sd_wT, &m->sd_b};
+  for (VecW* v : vecs) resolve(m, *v);
+  ConvW* convs[] = {&m->map_in, &m->qkv, &m->att_dense, &m->ffn, &m->ffn_out, &m->bert_encoder, &m->f0_proj, &m->n_proj,
+                    &m->f0_conv, &m->n_conv, &m->asr_res, &m->conv_post};
+  for (ConvW* cw : convs) resolve(m, *cw);
+  for (auto& l : m->dur_lstms) resolve(m, l);
+  resolve(m, m->pred_lstm); resolve(m, m->shared_lstm); resolve(m, m->text_lstm);
+  for (int i = 0; i < 3; ++i) { resolve(m, m->f0blk[i]); resolve(m, m->nblk[i]); }
+  for (auto& cw : m->te_cnn) resolve(m, cw);
+  for (auto& v : m->te_ln_w) resolve(m, v);
+  for (auto& v : m->te_ln_b) resolve(m, v);
+  resolve(m, m->enc);
+  for (int i = 0; i < 4; ++i) resolve(m, m->dec[i]);
+  for (int i = 0; i < c.n_upsamples; ++i) { resolve(m, m->noise_conv[i]); resolve(m, m->ups[i]); resolve(m, m->noise_res[i]); }
+  for (auto& r : m->resblocks) resolve(m, r);
+  m->host.clear();
+  m->pack.clear();
+  m->pack.shrink_to_fit();
+  m->finalized = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  int ld = 0;
+  long long bs = 0;
+  int rows = 0;
+  int dtype = KK_F32;
+  Buf slice(int coff) const {
+    Buf r = *this;
+    r.p = p ? (char*)p + (size_t)coff * (dtype == KK_F32 ? 4 : 2) : nullptr;
+    return r;
+  }
+  Buf row_offset(int r0) const {
+    Buf r = *this;
+    r.p = p ? (char*)p + (size_t)r0 * ld * (dtype == KK_F32 ? 4 : 2) : nullptr;
+    r.rows = rows - r0;
+    return r;
+  }
+};
+
+struct ConvOpt {
+  int mode = KK_CONV, stride = 1, pad = 0, dil = 1, in_shift = 0;
+  float in_slope = 1.f;
+  int act = KK_ACT_NONE;
+  float act_slope = 0.f;
+  float scale = 1.f;
+  int accumulate = 0;
+  const Buf* res = nullptr;
+};
+
+struct Ctx {
+  kk_model* m;
+  hipStream_t st;
+  bool dry;
+  char* base;
+  size_t cap, used = 0;
+  int B;
+  int adt;
+
+  void* raw(size_t bytes) {
+    const size_t off = (used + 255) & ~(size_t)255;
+    used = off + bytes;
+    return base ? base + off : nullptr;
+  }
+  Buf act(int rows, int ld, int dtype = -1) {
+    Buf b;
+    b.dtype = dtype < 0 ? adt : dtype;
+    b.ld = ld;
+    b.rows = rows;
+    b.bs = (long long)rows * ld;
+    b.p = raw((size_t)B * rows * ld * (b.dtype == KK_F32 ? 4 : 2));
+    return b;
+  }
+  float* f32(size_t n) { return (float*)raw(n * 4); }
+  int* i32(size_t n) { return (int*)raw(n * 4); }
+
+  int dbg(const char* name, const Buf& b, int C) {
+    if (dry) return 0;
+    auto it = m->dbg_over.find(name);
+    if (it != m->dbg_over.end())
+      KK_TRY(kk_launch_convert(it->second, KK_F32, (long long)b.rows * C, C, b.p, b.dtype, b.bs, b.ld, C, b.rows, B, st));
+    m->dbg[name] = DebugEntry{b.p, b.ld, b.bs, b.rows, C, b.dtype, B};
+    return 0;
+  }
+
+  int conv(const ConvW& w, const Buf& x, KKLen lin, const Buf& out, KKLen lout, int Q, const ConvOpt& o) {
+    if (dry) return 0;
+    KKConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x.p; a.xbs = x.bs; a.ldx = x.ld;
+    a.w = w.w; a.ldw = w.ldw; a.bias = w.b;
+    a.out = out.p; a.obs = out.bs; a.ldo = out.ld;
+    if (o.res) { a.res = o.res->p; a.rbs = o.res->bs; a.ldr = o.res->ld; }
+    a.Cin = w.Cin; a.Cout = w.Cout; a.Kw = w.Kw;
+    a.mode = o.mode; a.stride = o.stride; a.pad = o.pad; a.dil = o.dil; a.in_shift = o.in_shift;
+    a.Q = Q; a.Lo_rows = out.rows;
+    a.lin = lin; a.lout = lout;
+    a.in_slope = o.in_slope; a.scale = o.scale; a.accumulate = o.accumulate; a.act = o.act; a.act_slope = o.act_slope;
+    return kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
+  }
+
+  // scratch for instance-norm statistics, sized for the largest request seen in the dry run
+  float* st_partial = nullptr;
+  float* st_mean = nullptr;
+  float* st_rstd = nullptr;
+  static constexpr int ROWS_PER_CHUNK = 512;
+
+  int stats(const Buf& x, int C, int Lmax, KKLen len) {
+    if (dry) return 0;
+    KKStatsArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x.p; a.xbs = x.bs; a.ldx = x.ld; a.C = C; a.Lmax = Lmax; a.len = len;
+    a.partial = st_partial; a.rows_per_chunk = ROWS_PER_CHUNK; a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
+    return kk_launch_instnorm_stats(a, B, x.dtype, st);
+  }
+  int adain(const Buf& x, int C, KKLen len_in, const Buf& out, int Cpad, int Lmax_out, const float* gb, int gbs, int act, float slope,
+            const float* alpha, int pool, const float* pool_w, const float* pool_b) {
+    if (dry) return 0;
+    KKAdainArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x.p; a.xbs = x.bs; a.ldx = x.ld; a.out = out.p; a.obs = out.bs; a.ldo = out.ld;
+    a.C = C; a.Cpad = Cpad; a.Lmax_out = Lmax_out; a.len_in = len_in;
+    a.mean = st_mean; a.rstd = st_rstd; a.gb = gb; a.gbs = gbs; a.act = act; a.slope = slope; a.alpha = alpha;
+    a.pool = pool; a.pool_w = pool_w; a.pool_b = pool_b; a.fast = adt == KK_BF16;
+    return kk_launch_adain_act(a, B, x.dtype, st);
+  }
+  int layernorm(const Buf& x, const Buf* res, const Buf& out, int C, int Lmax, KKLen len, const float* w, const float* b, const float* gb,
+                int gbs, float eps, int act, float slope) {
+    if (dry) return 0;
+    KKLnArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x.p; a.xbs = x.bs; a.ldx = x.ld;
+    if (res) { a.res = res->p; a.rbs = res->bs; a.ldr = res->ld; }
+    a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.C = C; a.Lmax = Lmax; a.len = len; a.w = w; a.bias = b; a.gb = gb; a.gbs = gbs;
+    a.eps = eps; a.act = act; a.slope = slope;
+    return kk_launch_layernorm(a, B, x.dtype, st);
+  }
+  int lstm(const LstmW& l, const Buf& x, int Cin_ld_unused, float* xproj, const Buf& out, int Lmax, KKLen len) {
+    (void)Cin_ld_unused;
+    if (dry) return 0;
+    Buf xp;
+    xp.p = xproj; xp.ld = 8 * l.H; xp.bs = (long long)Lmax * 8 * l.H; xp.rows = Lmax; xp.dtype = KK_F32;
+    ConvOpt o;
+    KK_TRY(conv(l.in, x, len, xp, len, Lmax, o));
+    KKLstmArgs a;
+    memset(&a, 0, sizeof a);
+    a.xproj = xproj; a.whT = l.whT.p; a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.H = l.H; a.Lmax = Lmax; a.len = len;
+    return kk_launch_lstm(a, B, out.dtype, st);
+  }
+};
+
+static int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// AdainResBlk1d (istftnet.py:825-899).  x: [B][Lmax_in][>=Cin]; out: channel slice receiving Cout channels at Lout rows.
+int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in, const Buf& out, const float* style, int gbs,
+                 Buf& bufA, Buf& bufB, Buf& bufC) {
+  const int Lmax_out = r.up ? 2 * Lmax_in : Lmax_in;
+  KKLen lout = lin;
+  if (r.up) { lout.mul = lin.mul * 2; lout.add = lin.add * 2; }
+  KK_TRY(c.stats(x, r.Cin, Lmax_in, lin));
+  KK_TRY(c.adain(x, r.Cin, lin, bufA, rup(r.Cin, 32) <= bufA.ld ? rup(r.Cin, 32) : r.Cin, Lmax_out, style + r.n1.off, gbs, KK_ACT_LRELU,
+                 0.2f, nullptr, r.up ? 1 : 0, r.pool_w.p, r.pool_b.p));
+  ConvOpt o1;
+  o1.pad = 1;
+  KK_TRY(c.conv(r.conv1, bufA, lout, bufB, lout, Lmax_out, o1));
+  KK_TRY(c.stats(bufB, r.Cout, Lmax_out, lout));
+  KK_TRY(c.adain(bufB, r.Cout, lout, bufC, r.Cout, Lmax_out, style + r.n2.off, gbs, KK_ACT_LRELU, 0.2f, nullptr, 0, nullptr, nullptr));
+  ConvOpt o2;
+  o2.pad = 1;
+  o2.scale = 0.70710678118654752440f;  // / sqrt(2), istftnet.py:898
+  if (r.learned) {
+    ConvOpt os;
+    os.in_shift = r.up ? 1 : 0;  // nearest x2 up-sampling of the shortcut input (istftnet.py:863-866)
+    KK_TRY(c.conv(r.sc, x, lin, out, lout, Lmax_out, os));
+    o2.res = &out;
+  } else {
+    o2.res = &x;
+  }
+  KK_TRY(c.conv(r.conv2, bufC, lout, out, lout, Lmax_out, o2));
+  return 0;
+}
+
+// AdaINResBlock1 (istftnet.py:377-396).  Iteration 0 reads x_in; iterations keep their running value in y.
+// If acc != null the last iteration writes acc (+)= (conv + y) * acc_scale instead of y.
+int run_resblock1(Ctx& c, const ResBlock1& r, const Buf& x_in, const Buf& y, Buf& t1, Buf& t2, int Lmax, KKLen len, const float* style,
+                  int gbs, const Buf* acc, float acc_scale, int acc_accumulate) {
+  for (int j = 0; j < 3; ++j) {
+    const Buf& src = j == 0 ? x_in : y;
+    KK_TRY(c.stats(src, r.C, Lmax, len));
+    KK_TRY(c.adain(src, r.C, len, t1, r.C, Lmax, style + r.a1[j].off, gbs, KK_ACT_SNAKE, 0.f, r.al1[j].p, 0, nullptr, nullptr));
+    ConvOpt o1;
+    o1.dil = r.dil[j];
+    o1.pad = (r.k * r.dil[j] - r.dil[j]) / 2;
+    KK_TRY(c.conv(r.c1[j], t1, len, t2, len, Lmax, o1));
+    KK_TRY(c.stats(t2, r.C, Lmax, len));
+    KK_TRY(c.adain(t2, r.C, len, t1, r.C, Lmax, style + r.a2[j].off, gbs, KK_ACT_SNAKE, 0.f, r.al2[j].p, 0, nullptr, nullptr));
+    ConvOpt o2;
+    o2.pad = (r.k - 1) / 2;
+    o2.res = &src;
+    if (j == 2 && acc) {
+      o2.scale = acc_scale;
+      o2.accumulate = acc_accumulate;
+      KK_TRY(c.conv(r.c2[j], t1, len, *acc, len, Lmax, o2));
+    } else {
+      KK_TRY(c.conv(r.c2[j], t1, len, y, len, Lmax, o2));
+    }
+  }
+  return 0;
+}
+
+struct TextState {  // results of the text stage that the audio stage consumes
+  Buf d, t_en;
+  int* pred_dur = nullptr;
+};
+
+int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref_s, const float* speed, TextState& ts, int* pred_dur_out) {
+  kk_model* m = c.m;
+  const kk_config& cf = m->cfg;
+  const int H = cf.hidden_dim, hs = cf.plbert_hidden, E = cf.plbert_embedding, B = c.B;
+  const KKLen lT{lens, 1, 0};
+  // ---- Albert
+  Buf e = c.act(Tmax, E), x = c.act(Tmax, hs), qkv = c.act(Tmax, 3 * hs), ctxb = c.act(Tmax, hs), att = c.act(Tmax, hs),
+      ff = c.act(Tmax, cf.plbert_intermediate), tmp = c.act(Tmax, hs);
+  if (!c.dry) {
+    KKEmbedArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.ids = ids; ea.word = m->emb_word.p; ea.pos = m->emb_pos.p; ea.type = m->emb_type.p; ea.ln_w = m->emb_ln_w.p; ea.ln_b = m->emb_ln_b.p;
+    ea.out = e.p; ea.obs = e.bs; ea.ldo = e.ld; ea.E = E; ea.Tmax = Tmax; ea.len = lT; ea.eps = 1e-12f;
+    KK_TRY(kk_launch_albert_embed(ea, B, e.dtype, c.st));
+  }
+  ConvOpt plain;
+  KK_TRY(c.conv(m->map_in, e, lT, x, lT, Tmax, plain));
+  for (int layer = 0; layer < cf.plbert_layers; ++layer) {
+    KK_TRY(c.conv(m->qkv, x, lT, qkv, lT, Tmax, plain));
+    if (!c.dry) {
+      KKAttnArgs aa;
+      memset(&aa, 0, sizeof aa);
+      aa.qkv = qkv.p; aa.bs = qkv.bs; aa.ld = qkv.ld; aa.out = ctxb.p; aa.obs = ctxb.bs; aa.ldo = ctxb.ld;
+      aa.heads = cf.plbert_heads; aa.hs = hs; aa.Tmax = Tmax; aa.len = lT; aa.scale = 0.125f;
+      KK_TRY(kk_launch_attention(aa, B, qkv.dtype, c.st));
+    }
+    KK_TRY(c.conv(m->att_dense, ctxb, lT, tmp, lT, Tmax, plain));
+    KK_TRY(c.layernorm(tmp, &x, att, hs, Tmax, lT, m->att_ln_w.p, m->att_ln_b.p, nullptr, 0, 1e-12f, KK_ACT_NONE, 0.f));
+    ConvOpt gelu;
+    gelu.act = KK_ACT_GELU;
+    KK_TRY(c.conv(m->ffn, att, lT, ff, lT, Tmax, gelu));
+    KK_TRY(c.conv(m->ffn_out, ff, lT, tmp, lT, Tmax, plain));
+    KK_TRY(c.layernorm(tmp, &att, x, hs, Tmax, lT, m->full_ln_w.p, m->full_ln_b.p, nullptr, 0, 1e-12f, KK_ACT_NONE, 0.f));
+  }
+  KK_TRY(c.dbg("bert_dur", x, hs));
+  // ---- bert_encoder + DurationEncoder (kokoro.py:143-146, modules.py:392-411)
+  const int S = cf.style_dim;
+  Buf cat = c.act(Tmax, H + S);
+  KK_TRY(c.conv(m->bert_encoder, x, lT, cat, lT, Tmax, plain));
+  float* style_p = c.f32((size_t)B * m->Np);
+  if (!c.dry) {
+    KK_TRY(kk_launch_fill_style(ref_s, 128, cat.p, cat.bs, cat.ld, H, S, Tmax, lT, B, cat.dtype, c.st));
+    KK_TRY(kk_launch_style_fc(ref_s, 128, m->sp_wT.p, m->sp_b.p, style_p, m->Np, B, c.st));
+  }
+  float* xproj = c.f32((size_t)B * Tmax * 4 * H);  // 8 * (H/2)
+  Buf h = c.act(Tmax, H);
+  for (int i = 0; i < cf.n_layer; ++i) {
+    KK_TRY(c.lstm(m->dur_lstms[i], cat, 0, xproj, h, Tmax, lT));
+    KK_TRY(c.layernorm(h, nullptr, cat, H, Tmax, lT, nullptr, nullptr, style_p + m->dur_adaln[i].off, m->Np, 1e-5f, KK_ACT_NONE, 0.f));
+  }
+  KK_TRY(c.dbg("d", cat, H + S));
+  // ---- duration head (kokoro.py:147-150)
+  KK_TRY(c.lstm(m->pred_lstm, cat, 0, xproj, h, Tmax, lT));
+  int* pred_dur = c.i32((size_t)B * Tmax);
+  float* dur_f = c.f32((size_t)B * Tmax);
+  if (!c.dry) {
+    KK_TRY(kk_launch_duration(h.p, h.bs, h.ld, m->dur_W.p, m->dur_b.p, H, cf.max_dur, speed, pred_dur, dur_f, Tmax, lT, B, h.dtype, c.st));
+    Buf df;
+    df.p = dur_f; df.ld = 1; df.bs = Tmax; df.rows = Tmax; df.dtype = KK_F32;
+    KK_TRY(c.dbg("duration", df, 1));
+    if (pred_dur_out &&
+        hipMemcpyAsync(pred_dur_out, pred_dur, (size_t)B * Tmax * 4, hipMemcpyDeviceToDevice, c.st) != hipSuccess)
+      return kk_fail("kk_forward_text: copy of pred_dur failed");
+  }
+  // ---- TextEncoder (modules.py:41-68)
+  Buf te = c.act(Tmax, H), te2 = c.act(Tmax, H), t_en = c.act(Tmax, H);
+  if (!c.dry) KK_TRY(kk_launch_embedding(ids, m->te_emb.p, te.p, te.bs, te.ld, H, Tmax, lT, B, te.dtype, c.st));
+  for (int i = 0; i < cf.n_layer; ++i) {
+    ConvOpt o;
+    o.pad = (cf.text_encoder_kernel_size - 1) / 2;
+    KK_TRY(c.conv(m->te_cnn[i], te, lT, te2, lT, Tmax, o));
+    KK_TRY(c.layernorm(te2, nullptr, te, H, Tmax, lT, m->te_ln_w[i].p, m->te_ln_b[i].p, nullptr, 0, 1e-5f, KK_ACT_LRELU, 0.2f));
+  }
+  KK_TRY(c.lstm(m->text_lstm, te, 0, xproj, t_en, Tmax, lT));
+  KK_TRY(c.dbg("t_en", t_en, H));
+  ts.d = cat;
+  ts.t_en = t_en;
+  ts.pred_dur = pred_dur;
+  return 0;
+}
+
+int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* dur, int Fmax, int noise_mode, const float* noise,
+              uint64_t seed, const TextState& ts, float* wav_out, int* nframes_out) {
+  kk_model* m = c.m;
+  const kk_config& cf = m->cfg;
+  const int H = cf.hidden_dim, S = cf.style_dim, DH = cf.decoder_hidden, B = c.B;
+  const int u0 = cf.upsample_rates[0], u1 = cf.upsample_rates[1], hop = cf.gen_istft_hop_size;
+  const int L2 = 2 * Fmax, L20 = L2 * u0, Tf = L20 * u1 + 1, Nw = L20 * u1 * hop;
+  const int C0 = cf.upsample_initial_channel, nk = cf.n_resblock_kernels;
+  // ---- alignment + length regulation (kokoro.py:151-157,162)
+  int* frame_idx = c.i32((size_t)B * Fmax);
+  int* lenF = c.i32(B);
+  int* lens4 = c.i32((size_t)4 * B);
+  if (!c.dry) {
+    KK_TRY(kk_launch_alignment(dur, Tmax, lens, frame_idx, lenF, Fmax, B, c.st));
+    KK_TRY(kk_launch_lens(lenF, lens4, B, u0, u1, hop, c.st));
+    if (nframes_out && hipMemcpyAsync(nframes_out, lenF, (size_t)B * 4, hipMemcpyDeviceToDevice, c.st) != hipSuccess)
+      return kk_fail("kk_forward_audio: copy of nframes failed");
+  }
+  const KKLen lF{lenF, 1, 0}, l2{lenF, 2, 0}, l20{lenF, 2 * u0, 0}, lTf{lens4 + 2 * B, 1, 0}, lTfm1{lenF, 2 * u0 * u1, 0};
+  Buf en = c.act(Fmax, H + S);
+  const int ld514 = rup(H + 2, 32), ldcat = rup(DH + 2 + 64, 32);
+  Buf cat514 = c.act(Fmax, ld514);
+  if (!c.dry) {
+    KK_TRY(kk_launch_gather_rows(ts.d.p, ts.d.bs, ts.d.ld, frame_idx, Fmax, lenF, en.p, en.bs, en.ld, 0, H + S, B, en.dtype, c.st));
+    KK_TRY(kk_launch_gather_rows(ts.t_en.p, ts.t_en.bs, ts.t_en.ld, frame_idx, Fmax, lenF, cat514.p, cat514.bs, cat514.ld, 0, H, B,
+                                 cat514.dtype, c.st));
+  }
+  KK_TRY(c.dbg("en", en, H + S));
+  KK_TRY(c.dbg("asr", cat514, H));
+  float* style_p = c.f32((size_t)B * m->Np);
+  float* style_d = c.f32((size_t)B * m->Nd);
+  if (!c.dry) {
+    KK_TRY(kk_launch_style_fc(ref_s, 128, m->sp_wT.p, m->sp_b.p, style_p, m->Np, B, c.st));
+    KK_TRY(kk_launch_style_fc(ref_s, 0, m->sd_wT.p, m->sd_b.p, style_d, m->Nd, B, c.st));
+  }
+  // statistics scratch, sized for the largest (rows, channels) pair normalised below
+  {
+    // upper bounds: partial = B * chunks(L) * 2 * C for every (L, C) pair used below
+    size_t pmax = 0, cmax = 0;
+    auto upd = [&](int L, int C) {
+      pmax = std::max(pmax, kk_stats_partial_floats(B, C, L, Ctx::ROWS_PER_CHUNK));
+      cmax = std::max(cmax, (size_t)B * C);
+    };
+    upd(Fmax, H); upd(L2, H); upd(L2, H / 2); upd(Fmax, H + 2); upd(Fmax, DH + 2 + 64); upd(Fmax, DH); upd(L2, DH + 2 + 64);
+    upd(L2, H); upd(L20, C0 / 2); upd(Tf, C0 / 4);
+    c.st_partial = c.f32(pmax);
+    c.st_mean = c.f32(cmax);
+    c.st_rstd = c.f32(cmax);
+  }
+  // ---- F0Ntrain (modules.py:355-377)
+  float* xprojF = c.f32((size_t)B * Fmax * 4 * H);
+  Buf xs = c.act(Fmax, H);
+  KK_TRY(c.lstm(m->shared_lstm, en, 0, xprojF, xs, Fmax, lF));
+  Buf pA = c.act(L2, H), pB = c.act(L2, H), pC = c.act(L2, H), y0 = c.act(Fmax, H), y1 = c.act(L2, H / 2), y2 = c.act(L2, H / 2);
+  Buf f0n[2];
+  for (int which = 0; which < 2; ++which) {
+    const ResBlk1d* blk = which == 0 ? m->f0blk : m->nblk;
+    KK_TRY(run_resblk1d(c, blk[0], xs, lF, Fmax, y0, style_p, m->Np, pA, pB, pC));
+    KK_TRY(run_resblk1d(c, blk[1], y0, lF, Fmax, y1, style_p, m->Np, pA, pB, pC));
+    KK_TRY(run_resblk1d(c, blk[2], y1, l2, L2, y2, style_p, m->Np, pA, pB, pC));
+    f0n[which] = c.act(L2, 1, KK_F32);  // the F0 / N curves stay fp32 in every mode (phase accuracy)
+    ConvOpt o;
+    KK_TRY(c.conv(which == 0 ? m->f0_proj : m->n_proj, y2, l2, f0n[which], l2, L2, o));
+  }
+  KK_TRY(c.dbg("F0_pred", f0n[0], 1));
+  KK_TRY(c.dbg("N_pred", f0n[1], 1));
+  // ---- Decoder (istftnet.py:947-963)
+  Buf catA = c.act(Fmax, ldcat), catB = c.act(Fmax, ldcat);
+  {
+    ConvOpt o;
+    o.stride = 2;
+    o.pad = 1;
+    Buf dsts[3] = {cat514.slice(H), catA.slice(DH + 64), catB.slice(DH + 64)};
+    for (int k = 0; k < 3; ++k) {
+      KK_TRY(c.conv(m->f0_conv, f0n[0], l2, dsts[k], lF, Fmax, o));
+      KK_TRY(c.conv(m->n_conv, f0n[1], l2, dsts[k].slice(1), lF, Fmax, o));
+    }
+    ConvOpt p;
+    Buf a1 = catA.slice(DH), a2 = catB.slice(DH);
+    KK_TRY(c.conv(m->asr_res, cat514, lF, a1, lF, Fmax, p));
+    KK_TRY(c.conv(m->asr_res, cat514, lF, a2, lF, Fmax, p));
+  }
+  Buf dA = c.act(L2, ldcat), dB = c.act(L2, DH), dC = c.act(L2, DH);
+  KK_TRY(run_resblk1d(c, m->enc, cat514, lF, Fmax, catA, style_d, m->Nd, dA, dB, dC));
+  KK_TRY(c.dbg("dec_encode", catA, DH));
+  KK_TRY(run_resblk1d(c, m->dec[0], catA, lF, Fmax, catB, style_d, m->Nd, dA, dB, dC));
+  KK_TRY(run_resblk1d(c, m->dec[1], catB, lF, Fmax, catA, style_d, m->Nd, dA, dB, dC));
+  KK_TRY(run_resblk1d(c, m->dec[2], catA, lF, Fmax, catB, style_d, m->Nd, dA, dB, dC));
+  Buf gx = c.act(L2, H);
+  KK_TRY(run_resblk1d(c, m->dec[3], catB, lF, Fmax, gx, style_d, m->Nd, dA, dB, dC));
+  KK_TRY(c.dbg("dec_out", gx, H));
+  // ---- Generator front end (istftnet.py:770-775)
+  float* phase = c.f32((size_t)B * 9 * L2);
+  float* har_source = c.f32((size_t)B * Nw);
+  Buf har = c.act(Tf, 24);
+  if (!c.dry) {
+    KKSourceArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.f0 = (const float*)f0n[0].p; sa.L2max = L2; sa.len2 = lens4; sa.phase = phase; sa.lin_w = m->lin_w.p; sa.lin_b = m->lin_b;
+    sa.noise = noise; sa.seed = seed; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
+    KK_TRY(kk_launch_source(sa, B, c.st));
+    Buf hsb;
+    hsb.p = har_source; hsb.ld = 1; hsb.bs = Nw; hsb.rows = Nw; hsb.dtype = KK_F32;
+    KK_TRY(c.dbg("har_source", hsb, 1));
+    KK_TRY(kk_launch_stft20(har_source, Nw, lens4 + 3 * B, har.p, har.bs, har.ld, Tf, B, har.dtype, c.st));
+  }
+  KK_TRY(c.dbg("har", har, 22));
+  // ---- up-sampling stages (istftnet.py:776-796)
+  Buf cur = gx;           // input of ups[i]
+  KKLen lcur = l2;
+  int Lcur = L2;
+  for (int i = 0; i < cf.n_upsamples; ++i) {
+    const int Cst = C0 >> (i + 1);
+    const bool last = i == cf.n_upsamples - 1;
+    const int Lst = last ? Tf : L20;
+    const KKLen lst = last ? lTf : l20;
+    Buf xsrc = c.act(Lst, Cst), t1 = c.act(Lst, Cst), t2 = c.act(Lst, Cst), xi = c.act(Lst, Cst), yb = c.act(Lst, Cst), accb = c.act(Lst, Cst);
+    ConvOpt on;
+    if (!last) {
+      int sf0 = 1;
+      for (int j = i + 1; j < cf.n_upsamples; ++j) sf0 *= cf.upsample_rates[j];
+      on.stride = sf0;
+      on.pad = (sf0 + 1) / 2;
+    }
+    KK_TRY(c.conv(m->noise_conv[i], har, lTf, xsrc, lst, Lst, on));
+    KK_TRY(run_resblock1(c, m->noise_res[i], xsrc, xsrc, t1, t2, Lst, lst, style_d, m->Nd, nullptr, 1.f, 0));
+    ConvOpt ou;
+    ou.mode = KK_CONVT;
+    ou.stride = cf.upsample_rates[i];
+    ou.pad = (cf.upsample_kernel_sizes[i] - cf.upsample_rates[i]) / 2;
+    ou.in_slope = 0.1f;
+    const int Qt = kk_cdiv(Lcur * cf.upsample_rates[i], cf.upsample_rates[i]);
+    if (!last) {
+      ou.res = &xsrc;
+      KK_TRY(c.conv(m->ups[i], cur, lcur, xi, lst, Qt, ou));
+    } else {
+      // zero left pad of one frame (istftnet.py:786-787, "ReflectionPad1d" = mx.pad) then + x_source:
+      // copy x_source, then accumulate the transposed conv one row further down.
+      if (!c.dry)
+        KK_TRY(kk_launch_copy_slice(xsrc.p, xsrc.bs, xsrc.ld, xi.p, xi.bs, xi.ld, 0, Cst, Lst, lst, B, xi.dtype, c.st));
+      ou.accumulate = 1;
+      Buf xi1 = xi.row_offset(1);
+      KK_TRY(c.conv(m->ups[i], cur, lcur, xi1, lTfm1, Qt, ou));
+    }
+    KK_TRY(c.dbg(i == 0 ? "gen_pre_res0" : "gen_pre_res1", xi, Cst));
+    for (int j = 0; j < nk; ++j)
+      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0));
+    KK_TRY(c.dbg(i == 0 ? "gen_stage0" : "gen_stage1", accb, Cst));
+    cur = accb;
+    lcur = lst;
+    Lcur = Lst;
+  }
+  // ---- conv_post + iSTFT head (istftnet.py:798-806)
+  Buf cp = c.act(Tf, 24);
+  ConvOpt op;
+  op.pad = 3;
+  op.in_slope = 0.01f;
+  KK_TRY(c.conv(m->conv_post, cur, lTf, cp, lTf, Tf, op));
+  KK_TRY(c.dbg("conv_post", cp, 22));
+  if (!c.dry)
+    KK_TRY(kk_launch_istft_head(cp.p, cp.bs, cp.ld, lens4 + 2 * B, Tf, wav_out, (long long)Nw, B, cp.dtype, c.adt == KK_BF16 ? 1 : 0, c.st));
+  return 0;
+}
+
+int check_common(kk_model* m, int B, int Tmax, const char* who) {
+  if (!m) return kk_fail("null model");
+  if (!m->finalized) return failf("%s: kk_finalize has not been called", who);
+  if (B <= 0 || Tmax <= 0 || Tmax > 512 || Tmax > m->cfg.plbert_max_pos) return failf("%s: need 0 < B, 0 < Tmax <= 512 (kokoro.py:131-134)", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax) {
+  if (!m || !m->finalized || B <= 0 || Tmax <= 0) return 0;
+  Ctx c;
+  c.m = const_cast<kk_model*>(m); c.st = nullptr; c.dry = true; c.base = nullptr; c.cap = 0; c.used = 0;
+  c.B = B;
+  c.adt = m->adt;
+  TextState ts;
+  if (run_text(c, Tmax, nullptr, nullptr, nullptr, nullptr, ts, nullptr) != 0) return 0;
+  if (Fmax > 0 && run_audio(c, Tmax, nullptr, nullptr, nullptr, Fmax, 0, nullptr, 0, ts, nullptr, nullptr) != 0) return 0;
+  return c.used + 256;
+}
+
+static int make_ctx(kk_model* m, void* stream, int B, void* ws, size_t ws_bytes, Ctx& c) {
+  c.m = m; c.st = (hipStream_t)stream; c.dry = false; c.base = (char*)ws; c.cap = ws_bytes; c.used = 0; c.B = B; c.adt = m->adt;
+  if (!ws) return kk_fail("workspace is null");
+  if (((uintptr_t)ws & 255) != 0) return kk_fail("workspace must be 256-byte aligned");
+  return 0;
+}
+
+extern "C" int kk_forward_text(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+                               const float* speed, void* workspace, size_t workspace_bytes, int32_t* pred_dur_out) {
+  KK_TRY(check_common(m, B, Tmax, "kk_forward_text"));
+  if (!ids || !lens || !ref_s || !speed) return kk_fail("kk_forward_text: null input");
+  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, 0)) return kk_fail("kk_forward_text: workspace too small");
+  Ctx c;
+  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
+  TextState ts;
+  return run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out);
+}
+
+extern "C" int kk_forward_audio(kk_model* m, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur,
+                                int Fmax, int noise_mode, const float* sine_noise, uint64_t seed, void* workspace, size_t workspace_bytes,
+                                float* wav_out, int32_t* nframes_out) {
+  KK_TRY(check_common(m, B, Tmax, "kk_forward_audio"));
+  if (!lens || !ref_s || !dur || !wav_out || Fmax <= 0) return kk_fail("kk_forward_audio: bad argument");
+  if (noise_mode == KK_NOISE_INJECTED && !sine_noise) return kk_fail("kk_forward_audio: KK_NOISE_INJECTED needs sine_noise");
+  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, Fmax)) return kk_fail("kk_forward_audio: workspace too small");
+  // replay the text stage's allocation plan (no launches) to find where its results live in the workspace
+  Ctx c;
+  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
+  TextState ts;
+  c.dry = true;
+  KK_TRY(run_text(c, Tmax, nullptr, nullptr, nullptr, nullptr, ts, nullptr));
+  c.dry = false;
+  return run_audio(c, Tmax, lens, ref_s, dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
+}
+
+extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+                          const float* speed, const int32_t* forced_dur, int Fmax, int noise_mode, const float* sine_noise, uint64_t seed,
+                          void* workspace, size_t workspace_bytes, float* wav_out, int32_t* pred_dur_out, int32_t* nframes_out) {
+  KK_TRY(check_common(m, B, Tmax, "kk_forward"));
+  if (!ids || !lens || !ref_s || !speed || !wav_out || Fmax <= 0) return kk_fail("kk_forward: bad argument");
+  if (noise_mode == KK_NOISE_INJECTED && !sine_noise) return kk_fail("kk_forward: KK_NOISE_INJECTED needs sine_noise");
+  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, Fmax)) return kk_fail("kk_forward: workspace too small");
+  Ctx c;
+  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
+  TextState ts;
+  KK_TRY(run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out));
+  return run_audio(c, Tmax, lens, ref_s, forced_dur ? forced_dur : ts.pred_dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-kernel entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int kk_op_conv1d(void* stream, int B, const void* x, int ldx, int Lin_rows, const int32_t* lin, const float* w_packed, int ldw,
+                            const float* bias, int Cin, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift,
+                            float in_slope, int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out,
+                            int ldo, int Lout_rows, const int32_t* lout, int in_dtype, int out_dtype) {
+  KKConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.xbs = (long long)Lin_rows * ldx; a.ldx = ldx; a.w = w_packed; a.ldw = ldw; a.bias = bias;
+  a.out = out; a.obs = (long long)Lout_rows * ldo; a.ldo = ldo;
+  a.res = res; a.rbs = (long long)Lout_rows * ldr; a.ldr = ldr;
+  a.Cin = Cin; a.Cout = Cout; a.Kw = Kw; a.mode = transposed ? KK_CONVT : KK_CONV; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.in_shift = in_shift; a.Q = transposed ? kk_cdiv(Lout_rows, stride) : Lout_rows; a.Lo_rows = Lout_rows;
+  a.lin = KKLen{lin, lin ? 1 : 0, lin ? 0 : Lin_rows};
+  a.lout = KKLen{lout, lout ? 1 : 0, lout ? 0 : Lout_rows};
+  a.in_slope = in_slope; a.scale = scale; a.accumulate = accumulate; a.act = act; a.act_slope = act_slope;
+  return kk_launch_conv_generic(a, B, in_dtype, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta,
+                           int gbs, int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out,
+                           int ldo, int Cpad, int Lout_rows, float* scratch, size_t scratch_floats, int dtype, int fast) {
+  const size_t np = kk_stats_partial_floats(B, C, L_rows, 512);
+  if (scratch_floats < np + 2 * (size_t)B * C) return kk_fail("kk_op_adain: scratch too small");
+  KKStatsArgs s;
+  memset(&s, 0, sizeof s);
+  s.x = x; s.xbs = (long long)L_rows * ldx; s.ldx = ldx; s.C = C; s.Lmax = L_rows; s.len = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
+  s.partial = scratch; s.rows_per_chunk = 512; s.mean = scratch + np; s.rstd = scratch + np + (size_t)B * C; s.eps = 1e-5f;
+  KK_TRY(kk_launch_instnorm_stats(s, B, dtype, (hipStream_t)stream));
+  KKAdainArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.xbs = s.xbs; a.ldx = ldx; a.out = out; a.obs = (long long)Lout_rows * ldo; a.ldo = ldo; a.C = C; a.Cpad = Cpad;
+  a.Lmax_out = Lout_rows; a.len_in = s.len; a.mean = s.mean; a.rstd = s.rstd; a.gb = gamma_beta; a.gbs = gbs; a.act = act; a.slope = slope;
+  a.alpha = alpha; a.pool = pool; a.pool_w = pool_w; a.pool_b = pool_b; a.fast = fast;
+  return kk_launch_adain_act(a, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_layernorm(void* stream, int B, const void* x, int ldx, const void* res, int ldr, int L_rows, const int32_t* len, int C,
+                               const float* w, const float* b, const float* gamma_beta, int gbs, float eps, int act, float slope, void* out,
+                               int ldo, int dtype) {
+  KKLnArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.xbs = (long long)L_rows * ldx; a.ldx = ldx; a.res = res; a.rbs = (long long)L_rows * ldr; a.ldr = ldr;
+  a.out = out; a.obs = (long long)L_rows * ldo; a.ldo = ldo; a.C = C; a.Lmax = L_rows; a.len = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
+  a.w = w; a.bias = b; a.gb = gamma_beta; a.gbs = gbs; a.eps = eps; a.act = act; a.slope = slope;
+  return kk_launch_layernorm(a, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_lstm(void* stream, int B, const float* xproj, const float* whT, int H, int L_rows, const int32_t* len, void* out,
+                          int ldo, int dtype) {
+  KKLstmArgs a;
+  memset(&a, 0, sizeof a);
+  a.xproj = xproj; a.whT = whT; a.out = out; a.obs = (long long)L_rows * ldo; a.ldo = ldo; a.H = H; a.Lmax = L_rows;
+  a.len = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
+  return kk_launch_lstm(a, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_attention(void* stream, int B, const void* qkv, int ld, int T_rows, const int32_t* len, int heads, void* out, int ldo,
+                               int dtype) {
+  KKAttnArgs a;
+  memset(&a, 0, sizeof a);
+  a.qkv = qkv; a.bs = (long long)T_rows * ld; a.ld = ld; a.out = out; a.obs = (long long)T_rows * ldo; a.ldo = ldo; a.heads = heads;
+  a.hs = heads * 64; a.Tmax = T_rows; a.len = KKLen{len, len ? 1 : 0, len ? 0 : T_rows}; a.scale = 0.125f;
+  return kk_launch_attention(a, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_source_stft(void* stream, int B, const float* f0, int L2_rows, const int32_t* len2, const float* lin_w9, float lin_b,
+                                 int noise_mode, const float* noise, uint64_t seed, float* phase_scratch, float* har_source, void* har,
+                                 int ldhar, int dtype) {
+  KKSourceArgs sa;
+  memset(&sa, 0, sizeof sa);
+  sa.f0 = f0; sa.L2max = L2_rows; sa.len2 = len2; sa.phase = phase_scratch; sa.lin_w = lin_w9; sa.lin_b = lin_b; sa.noise = noise;
+  sa.seed = seed; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = 300 * L2_rows; sa.upsample = 300;
+  KK_TRY(kk_launch_source(sa, B, (hipStream_t)stream));
+  if (len2) return kk_fail("kk_op_source_stft: ragged lengths are exercised through kk_forward only");
+  const int Tf = 60 * L2_rows + 1;
+  return kk_launch_stft20(har_source, sa.Nmax, nullptr, har, (long long)Tf * ldhar, ldhar, Tf, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_istft_head(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, float* wav, int dtype,
+                                int fast) {
+  return kk_launch_istft_head(x, (long long)Tf_rows * ldx, ldx, len_frames, Tf_rows, wav, (long long)5 * (Tf_rows - 1), B, dtype, fast,
+                              (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug hooks
+// ------------------------------------------------------------------------------------------------
+extern "C" int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channels) {
+  if (!m || !name) return kk_fail("kk_debug_info: null argument");
+  auto it = m->dbg.find(name);
+  if (it == m->dbg.end()) return failf("kk_debug_info: no intermediate named %s in the last forward", name);
+  if (rows) *rows = it->second.rows;
+  if (channels) *channels = it->second.C;
+  return 0;
+}
+extern "C" int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst) {
+  if (!m || !name || !dst) return kk_fail("kk_debug_fetch: null argument");
+  auto it = m->dbg.find(name);
+  if (it == m->dbg.end()) return failf("kk_debug_fetch: no intermediate named %s in the last forward", name);
+  const DebugEntry& e = it->second;
+  return kk_launch_convert(e.p, e.dtype, e.bs, e.ld, dst, KK_F32, (long long)e.rows * e.C, e.C, e.C, e.rows, e.B, (hipStream_t)stream);
+}
+extern "C" int kk_debug_override(kk_model* m, const char* name, const float* src) {
+  if (!m || !name || !src) return kk_fail("kk_debug_override: null argument");
+  m->dbg_over[name] = src;
+  return 0;
+}
+extern "C" void kk_debug_clear(kk_model* m) {
+  if (!m) return;
+  m->dbg_over.clear();
+  m->dbg.clear();
+}

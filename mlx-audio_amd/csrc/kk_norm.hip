@@ -1,0 +1,251 @@
+// Normalisation family on frames-major tensors:
+//   * instance-norm statistics over the valid frames of each (utterance, channel)
+//       -> InstanceNorm1d (istftnet.py:216-268, ddof 0, eps 1e-5)
+//   * AdaIN apply + activation (Snake / LeakyReLU), optionally followed by the depth-wise
+//     k3 s2 transposed conv + front zero pad of the up-sampling residual path
+//       -> AdaIN1d (istftnet.py:327-338), Snake (istftnet.py:382,389), AdainResBlk1d._residual
+//          (istftnet.py:874-882)
+//   * LayerNorm / AdaLayerNorm over channels (modules.py:33,71-90,448,480,566)
+#include "kk_common.h"
+#include "kk_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------- instance-norm statistics
+// partial[b][chunk][0|1][C]: sums of (x - shift) and (x - shift)^2 with shift = x[b][0][c]
+template <typename T>
+__global__ __launch_bounds__(256) void stats_partial_kernel(KKStatsArgs a, int cw) {
+  __shared__ float red[2][256];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int L = kk_len(a.len, b);
+  const int r0 = chunk * a.rows_per_chunk;
+  const int r1 = min(L, r0 + a.rows_per_chunk);
+  const int RL = 256 / cw;
+  const int cl = tid % cw, rl = tid / cw;
+  const T* xb = (const T*)a.x + (long long)b * a.xbs;
+  float* pb = a.partial + ((long long)b * a.nchunk + chunk) * 2 * a.C;
+  for (int cbase = 0; cbase < a.C; cbase += cw) {
+    const int c = cbase + cl;
+    float s = 0.f, ss = 0.f;
+    if (c < a.C && L > 0) {
+      const float shift = kk_ld(xb + c);
+      for (int r = r0 + rl; r < r1; r += RL) {
+        const float v = kk_ld(xb + (long long)r * a.ldx + c) - shift;
+        s += v;
+        ss = __builtin_fmaf(v, v, ss);
+      }
+    }
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
+    if (rl == 0 && c < a.C) {
+      for (int k = 1; k < RL; ++k) {
+        s += red[0][k * cw + cl];
+        ss += red[1][k * cw + cl];
+      }
+      pb[c] = s;
+      pb[a.C + c] = ss;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stats_final_kernel(KKStatsArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= a.C) return;
+  const int L = kk_len(a.len, b);
+  float mean = 0.f, rstd = 0.f;
+  if (L > 0) {
+    const int nch = kk_cdiv(L, a.rows_per_chunk);
+    double S = 0.0, SS = 0.0;
+    const float* pb = a.partial + (long long)b * a.nchunk * 2 * a.C;
+    for (int k = 0; k < nch; ++k) {
+      S += (double)pb[(long long)k * 2 * a.C + c];
+      SS += (double)pb[(long long)k * 2 * a.C + a.C + c];
+    }
+    const double shift = (double)kk_ld((const T*)a.x + (long long)b * a.xbs + c);
+    const double m = S / L;
+    double var = SS / L - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)(shift + m);
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  a.mean[(long long)b * a.C + c] = mean;
+  a.rstd[(long long)b * a.C + c] = rstd;
+}
+
+// ---------------------------------------------------------------- AdaIN apply (+ act, + pool)
+__device__ __forceinline__ float act_apply(float y, int act, float slope, float alpha, bool fast) {
+  if (act == KK_ACT_LRELU) return y > 0.f ? y : y * slope;
+  if (act == KK_ACT_SNAKE) {
+    const float s = fast ? __sinf(alpha * y) : sinf(alpha * y);
+    return y + (1.0f / alpha) * (s * s);
+  }
+  return y;
+}
+
+constexpr int ADAIN_ROWS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void adain_act_kernel(KKAdainArgs a) {
+  extern __shared__ float prm[];  // [5][C]: mean, rstd, 1+gamma, beta, alpha
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int C = a.C;
+  float* p_mean = prm;
+  float* p_rstd = prm + C;
+  float* p_g = prm + 2 * C;
+  float* p_b = prm + 3 * C;
+  float* p_al = prm + 4 * C;
+  for (int c = tid; c < C; c += 256) {
+    p_mean[c] = a.mean[(long long)b * C + c];
+    p_rstd[c] = a.rstd[(long long)b * C + c];
+    p_g[c] = 1.0f + a.gb[(long long)b * a.gbs + c];
+    p_b[c] = a.gb[(long long)b * a.gbs + C + c];
+    p_al[c] = a.alpha ? a.alpha[c] : 1.0f;
+  }
+  __syncthreads();
+  const int Lin = kk_len(a.len_in, b);
+  const int Lout = a.pool ? 2 * Lin : Lin;
+  const int row0 = blockIdx.x * ADAIN_ROWS;
+  const T* xb = (const T*)a.x + (long long)b * a.xbs;
+  T* ob = (T*)a.out + (long long)b * a.obs;
+  const int total = ADAIN_ROWS * a.Cpad;
+  for (int e = tid; e < total; e += 256) {
+    const int rr = e / a.Cpad, c = e - rr * a.Cpad;
+    const int row = row0 + rr;
+    if (row >= a.Lmax_out) break;
+    float v = 0.f;
+    if (row < Lout && c < C) {
+      if (!a.pool) {
+        const float xn = (kk_ld(xb + (long long)row * a.ldx + c) - p_mean[c]) * p_rstd[c];
+        v = act_apply(xn * p_g[c] + p_b[c], a.act, a.slope, p_al[c], a.fast != 0);
+      } else if (row > 0) {
+        // depth-wise ConvTranspose1d(k3, s2, p1) then one zero row in FRONT (istftnet.py:880-881):
+        // out[j], j' = j-1:  even j'=2m -> y[m]*w1 ; odd j'=2m+1 -> y[m]*w2 + y[m+1]*w0 ; + bias
+        const int jp = row - 1, m = jp >> 1;
+        const float y0 = act_apply((kk_ld(xb + (long long)m * a.ldx + c) - p_mean[c]) * p_rstd[c] * p_g[c] + p_b[c], a.act,
+                                   a.slope, p_al[c], a.fast != 0);
+        const float* w3 = a.pool_w + 3 * c;
+        if ((jp & 1) == 0) {
+          v = y0 * w3[1] + a.pool_b[c];
+        } else {
+          float acc = y0 * w3[2];
+          if (m + 1 < Lin) {
+            const float y1 = act_apply(
+                (kk_ld(xb + (long long)(m + 1) * a.ldx + c) - p_mean[c]) * p_rstd[c] * p_g[c] + p_b[c], a.act, a.slope, p_al[c],
+                a.fast != 0);
+            acc += y1 * w3[0];
+          }
+          v = acc + a.pool_b[c];
+        }
+      }
+    }
+    kk_st(ob + (long long)row * a.ldo + c, v);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm over channels (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(KKLnArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wv, b = blockIdx.y;
+  if (row >= a.Lmax) return;
+  const int L = kk_len(a.len, b);
+  T* orow = (T*)a.out + (long long)b * a.obs + (long long)row * a.ldo;
+  if (row >= L) {
+    for (int c = lane; c < a.C; c += 64) kk_st(orow + c, 0.f);
+    return;
+  }
+  const T* xr = (const T*)a.x + (long long)b * a.xbs + (long long)row * a.ldx;
+  const T* rr = a.res ? (const T*)a.res + (long long)b * a.rbs + (long long)row * a.ldr : nullptr;
+  constexpr int MAXV = 32;  // C <= 2048
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < a.C) {
+      t = kk_ld(xr + c);
+      if (rr) t += kk_ld(rr + c);
+    }
+    v[i] = t;
+    s += t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)a.C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < a.C) {
+      const float d = v[i] - mean;
+      ss = __builtin_fmaf(d, d, ss);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss / (float)a.C + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < a.C) {
+      float y = (v[i] - mean) * rstd;
+      if (a.gb) y = (1.0f + a.gb[(long long)b * a.gbs + c]) * y + a.gb[(long long)b * a.gbs + a.C + c];
+      else y = y * a.w[c] + a.bias[c];
+      if (a.act == KK_ACT_LRELU) y = y > 0.f ? y : y * a.slope;
+      kk_st(orow + c, y);
+    }
+  }
+}
+
+}  // namespace
+
+size_t kk_stats_partial_floats(int B, int C, int Lmax, int rows_per_chunk) {
+  return (size_t)B * kk_cdiv(Lmax, rows_per_chunk) * 2 * C;
+}
+
+int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
+  if (B <= 0 || a.C <= 0) return 0;
+  a.nchunk = kk_cdiv(a.Lmax, a.rows_per_chunk);
+  if (a.nchunk <= 0) a.nchunk = 1;
+  const int cw = a.C >= 256 ? 256 : (a.C > 64 ? 128 : 64);
+  dim3 g1(a.nchunk, B), g2(kk_cdiv(a.C, 256), B);
+  if (dtype == KK_F32) {
+    hipLaunchKernelGGL(stats_partial_kernel<float>, g1, dim3(256), 0, st, a, cw);
+    hipLaunchKernelGGL(stats_final_kernel<float>, g2, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, a, cw);
+    hipLaunchKernelGGL(stats_final_kernel<bf16_t>, g2, dim3(256), 0, st, a);
+  }
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
+int kk_launch_adain_act(const KKAdainArgs& a, int B, int dtype, hipStream_t st) {
+  if (B <= 0 || a.Lmax_out <= 0) return 0;
+  if (a.C > 2048) return kk_fail("adain_act: C > 2048");
+  dim3 grid(kk_cdiv(a.Lmax_out, ADAIN_ROWS), B);
+  const size_t sh = (size_t)5 * a.C * sizeof(float);
+  if (dtype == KK_F32)
+    hipLaunchKernelGGL(adain_act_kernel<float>, grid, dim3(256), sh, st, a);
+  else
+    hipLaunchKernelGGL(adain_act_kernel<bf16_t>, grid, dim3(256), sh, st, a);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
+int kk_launch_layernorm(const KKLnArgs& a, int B, int dtype, hipStream_t st) {
+  if (B <= 0 || a.Lmax <= 0) return 0;
+  if (a.C > 2048) return kk_fail("layernorm: C > 2048");
+  dim3 grid(kk_cdiv(a.Lmax, 4), B);
+  if (dtype == KK_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  KK_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,306 @@
+// Harmonic source, forward STFT(20) and the iSTFT vocoder head.
+//
+//  kk_launch_source  : SineGen + SourceModuleHnNSF (istftnet.py:531-680) with the 300x nearest F0
+//                      up-sampling of Generator.__call__ (istftnet.py:770) folded in.
+//  kk_launch_stft20  : MLXSTFT.transform (istftnet.py:463-495) + stft (utils.py:52-101).
+//  kk_launch_istft_head : spec=exp / phase=sin (istftnet.py:804-805) + MLXSTFT.inverse
+//                      (istftnet.py:497-523) + istft (utils.py:104-158).
+//
+// Float32 operation order follows the reference wherever it changes the result materially (the
+// phase accumulator reaches 1e5..1e6 rad, where one float32 ulp is 0.01..0.1 rad): sequential
+// cumsum, (cumsum*2)*pi*300, the un-clamped linear interpolation with its wrap to the LAST sample
+// for the first 150 outputs (interpolate.py:88-106), un-fused multiply/add in the blend.
+#include "kk_common.h"
+#include "kk_kernels.h"
+
+namespace {
+
+struct Tables {
+  float hann_sym[20];  // utils.py:10-14, forward STFT window
+  float hann_per[20];  // hanning(21)[:-1], utils.py:121, inverse window
+  float cs[20];        // cos(2*pi*m/20)
+  float sn[20];        // sin(2*pi*m/20)
+};
+
+Tables make_tables() {
+  Tables t;
+  const double pi = 3.14159265358979323846;
+  for (int n = 0; n < 20; ++n) {
+    t.hann_sym[n] = (float)(0.5 * (1.0 - cos(2.0 * pi * n / 19.0)));
+    t.hann_per[n] = (float)(0.5 * (1.0 - cos(2.0 * pi * n / 20.0)));
+    t.cs[n] = (float)cos(2.0 * pi * n / 20.0);
+    t.sn[n] = (float)sin(2.0 * pi * n / 20.0);
+  }
+  // exact values where they are exact
+  t.cs[0] = 1.f; t.cs[5] = 0.f; t.cs[10] = -1.f; t.cs[15] = 0.f;
+  t.sn[0] = 0.f; t.sn[5] = 1.f; t.sn[10] = 0.f; t.sn[15] = -1.f;
+  return t;
+}
+
+// ------------------------------------------------------------------ phase accumulator
+// phase[b][h][i] = ((cumsum_i(rad) * 2) * pi) * up, rad = python_mod(f0*h/24000, 1)   (istftnet.py:561,573-575)
+__global__ __launch_bounds__(64) void source_phase_kernel(KKSourceArgs a) {
+  __shared__ float f0s[1024];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int L2 = a.len2 ? a.len2[b] : a.L2max;
+  const float hmul = (float)(lane + 1);
+  float cum = 0.f;
+  float* ph = a.phase + ((long long)b * 9 + lane) * a.L2max;
+  for (int i0 = 0; i0 < L2; i0 += 1024) {
+    const int n = min(1024, L2 - i0);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) f0s[i] = a.f0[(long long)b * a.L2max + i0 + i];
+    __syncthreads();
+    if (lane < 9) {
+      for (int i = 0; i < n; ++i) {
+        const float fn = f0s[i] * hmul;
+        float r = fmodf(fn / 24000.0f, 1.0f);
+        if (r < 0.f) r += 1.0f;  // python-style modulo (result takes the sign of the divisor)
+        cum = cum + r;
+        ph[i0 + i] = ((cum * 2.0f) * 3.14159265358979323846f) * (float)a.upsample;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t sub, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), sub, 0x4B4B5352u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& z0, float& z1) {
+  const float a = ((float)(u0 >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+  const float bq = ((float)(u1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * __logf(a));
+  float s, c;
+  __sincosf(6.28318530717958647692f * bq, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+// ------------------------------------------------------------------ sample synthesis
+__global__ __launch_bounds__(256) void source_sample_kernel(KKSourceArgs a, float xs, float xh) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.Nmax) return;
+  const int L2 = a.len2 ? a.len2[b] : a.L2max;
+  const int N = L2 * a.upsample;
+  float* o = a.har_source + (long long)b * a.Nmax;
+  if (n >= N) {
+    o[n] = 0.f;
+    return;
+  }
+  // interpolate1d(linear, align_corners=None), interpolate.py:80-106
+  const float x = ((float)n * xs + xh) - 0.5f;
+  const float xl = floorf(x);
+  const int lo = (int)xl;
+  const int hi = min(lo + 1, L2 - 1);
+  const float fr = x - xl;
+  const int lo_w = lo < 0 ? lo + L2 : lo;  // negative index wraps to the end
+  const float omf = 1.0f - fr;
+  const float f0 = a.f0[(long long)b * a.L2max + n / a.upsample];
+  const float uv = f0 > 10.0f ? 1.0f : 0.0f;
+  const float namp = uv * 0.003f + ((1.0f - uv) * 0.1f) / 3.0f;
+  float nz[12];
+#pragma unroll
+  for (int h = 0; h < 12; ++h) nz[h] = 0.f;
+  if (a.noise_mode == 1) {
+    const float* np_ = a.noise + ((long long)b * a.Nmax + n) * 9;
+#pragma unroll
+    for (int h = 0; h < 9; ++h) nz[h] = np_[h];
+  } else if (a.noise_mode == 2) {
+    const uint64_t ctr = (uint64_t)b * (uint64_t)a.Nmax + (uint64_t)n;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      uint32_t r[4];
+      philox4(a.seed, ctr, (uint32_t)g, r);
+      box_muller(r[0], r[1], nz[4 * g], nz[4 * g + 1]);
+      box_muller(r[2], r[3], nz[4 * g + 2], nz[4 * g + 3]);
+    }
+  }
+  const float* pb = a.phase + (long long)b * 9 * a.L2max;
+  float acc = 0.f;
+#pragma unroll
+  for (int h = 0; h < 9; ++h) {
+    const float pl = pb[(long long)h * a.L2max + lo_w];
+    const float phh = pb[(long long)h * a.L2max + hi];
+    const float t0 = pl * omf;
+    const float t1 = phh * fr;
+    const float ph = t0 + t1;
+    const float sw = (sinf(ph) * 0.1f) * uv + namp * nz[h];
+    acc += sw * a.lin_w[h];
+  }
+  o[n] = tanhf(acc + a.lin_b);
+}
+
+// ------------------------------------------------------------------ forward STFT (n_fft 20, hop 5)
+template <typename T>
+__global__ __launch_bounds__(256) void stft20_kernel(const float* hs, int Nmax, const int* lenN, T* har, long long obs, int ldo,
+                                                     int Tfmax, Tables tb) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tfmax) return;
+  const int N = lenN ? lenN[b] : Nmax;
+  const int Tf = N > 0 ? N / 5 + 1 : 0;
+  T* o = har + (long long)b * obs + (long long)t * ldo;
+  if (t >= Tf) {
+#pragma unroll
+    for (int k = 0; k < 22; ++k) kk_st(o + k, 0.f);
+    return;
+  }
+  const float* x = hs + (long long)b * Nmax;
+  float fr[20];
+#pragma unroll
+  for (int j = 0; j < 20; ++j) {
+    int m = 5 * t + j - 10;
+    if (m < 0) m = -m;
+    if (m >= N) m = 2 * (N - 1) - m;
+    fr[j] = x[m] * tb.hann_sym[j];
+  }
+#pragma unroll
+  for (int k = 0; k <= 10; ++k) {
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+      const int m = (k * j) % 20;
+      re = __builtin_fmaf(fr[j], tb.cs[m], re);
+      im = __builtin_fmaf(-fr[j], tb.sn[m], im);
+    }
+    if (k == 0 || k == 10) im = 0.f;  // real FFT: DC / Nyquist carry a +0 imaginary part
+    kk_st(o + k, sqrtf(re * re + im * im));
+    kk_st(o + 11 + k, atan2f(im, re));
+  }
+}
+
+// ------------------------------------------------------------------ iSTFT head
+constexpr int IH_FR = 256;  // hop-blocks per workgroup
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
+                                                         long long wbs, Tables tb) {
+  __shared__ float ys[IH_FR + 3][21];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int Tf = len_frames ? len_frames[b] : Tfmax;
+  const int g0 = blockIdx.x * IH_FR;  // first hop-block of this workgroup
+  const T* xb = x + (long long)b * xbs;
+  // phase 1: windowed inverse real DFT of frames g0-3 .. g0+IH_FR-1
+  for (int i = tid; i < IH_FR + 3; i += 256) {
+    const int f = g0 - 3 + i;
+    if (f >= 0 && f < Tf) {
+      const T* xr = xb + (long long)f * ldx;
+      float re[11], im[11];
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float lm = kk_ld(xr + k), pr = kk_ld(xr + 11 + k);
+        const float mag = FAST ? __expf(lm) : expf(lm);
+        const float ph = FAST ? __sinf(pr) : sinf(pr);
+        float s, c;
+        if (FAST) __sincosf(ph, &s, &c); else sincosf(ph, &s, &c);
+        re[k] = mag * c;
+        im[k] = mag * s;
+      }
+#pragma unroll
+      for (int o = 0; o < 20; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 1; k < 10; ++k) {
+          const int m = (k * o) % 20;
+          acc = __builtin_fmaf(re[k], tb.cs[m], acc);
+          acc = __builtin_fmaf(-im[k], tb.sn[m], acc);
+        }
+        const float v = (re[0] + ((o & 1) ? -re[10] : re[10]) + 2.0f * acc) * 0.05f;
+        ys[i][o] = v * tb.hann_per[o];
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 20; ++o) ys[i][o] = 0.f;
+    }
+  }
+  __syncthreads();
+  // phase 2: overlap-add in ascending frame order, normalise by the window sum, trim 10 | 10
+  const int g = g0 + tid;
+  const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
+  float* wb = wav + (long long)b * wbs;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int n = 5 * g + r - 10;
+    if (n < 0 || n >= 5 * (Tfmax - 1)) continue;
+    float v = 0.f;
+    if (n < nout) {
+      float acc = 0.f, ws = 0.f;
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        const int f = g - j;
+        if (f >= 0 && f < Tf) {
+          acc += ys[tid + 3 - j][5 * j + r];
+          ws += tb.hann_per[5 * j + r];
+        }
+      }
+      v = ws != 0.f ? acc / ws : acc;
+    }
+    wb[n] = v;
+  }
+}
+
+const Tables g_tables = make_tables();
+
+}  // namespace
+
+int kk_launch_source(const KKSourceArgs& a, int B, hipStream_t st) {
+  if (B <= 0 || a.L2max <= 0) return 0;
+  hipLaunchKernelGGL(source_phase_kernel, dim3(B), dim3(64), 0, st, a);
+  // interpolate.py:84-86: x = arange(size) * (in_width/size) + 0.5*(in_width/size) - 0.5 ; in_width/size is the
+  // python double 2F/(600F) = fl64(1/up), converted to float32 when it meets the float32 array
+  const double r = 1.0 / (double)a.upsample;
+  const float xs = (float)r, xh = (float)(0.5 * r);
+  hipLaunchKernelGGL(source_sample_kernel, dim3(kk_cdiv(a.Nmax, 256), B), dim3(256), 0, st, a, xs, xh);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
+int kk_launch_stft20(const float* har_source, int Nmax, const int* lenN, void* har, long long obs, int ldo, int Tfmax, int B, int dtype,
+                     hipStream_t st) {
+  if (B <= 0 || Tfmax <= 0) return 0;
+  dim3 grid(kk_cdiv(Tfmax, 256), B);
+  if (dtype == KK_F32)
+    hipLaunchKernelGGL(stft20_kernel<float>, grid, dim3(256), 0, st, har_source, Nmax, lenN, (float*)har, obs, ldo, Tfmax, g_tables);
+  else
+    hipLaunchKernelGGL(stft20_kernel<bf16_t>, grid, dim3(256), 0, st, har_source, Nmax, lenN, (bf16_t*)har, obs, ldo, Tfmax, g_tables);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
+int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav, long long wbs, int B,
+                         int dtype, int fast, hipStream_t st) {
+  if (B <= 0 || Tfmax <= 0) return 0;
+  dim3 grid(kk_cdiv(Tfmax + 3, IH_FR), B);
+  if (dtype == KK_F32) {
+    if (fast)
+      hipLaunchKernelGGL((istft_head_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    else
+      hipLaunchKernelGGL((istft_head_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+  } else {
+    if (fast)
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    else
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+  }
+  KK_CHECK_LAUNCH();
+  return 0;
+}

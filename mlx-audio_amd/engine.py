@@ -1,0 +1,187 @@
+"""Batched device engine over the C ABI.  PyTorch is used for device memory and streams only;
+every arithmetic operation of the path runs in libkokoro_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KKConfig, check
+
+
+def make_kk_config(cfg: dict, compute_dtype: str = "float32") -> KKConfig:
+    ist, pb = cfg["istftnet"], cfg["plbert"]
+    k = KKConfig()
+    k.n_token, k.hidden_dim, k.style_dim, k.n_layer = cfg["n_token"], cfg["hidden_dim"], cfg["style_dim"], cfg["n_layer"]
+    k.max_dur, k.text_encoder_kernel_size = cfg["max_dur"], cfg["text_encoder_kernel_size"]
+    k.plbert_hidden, k.plbert_heads = pb["hidden_size"], pb["num_attention_heads"]
+    k.plbert_intermediate, k.plbert_max_pos = pb["intermediate_size"], pb["max_position_embeddings"]
+    k.plbert_layers, k.plbert_embedding = pb["num_hidden_layers"], pb.get("embedding_size", 128)
+    k.decoder_hidden = cfg.get("decoder_hidden", 1024)
+    k.upsample_initial_channel = ist["upsample_initial_channel"]
+    k.n_upsamples = len(ist["upsample_rates"])
+    for i, (u, ks) in enumerate(zip(ist["upsample_rates"], ist["upsample_kernel_sizes"])):
+        k.upsample_rates[i], k.upsample_kernel_sizes[i] = u, ks
+    k.n_resblock_kernels = len(ist["resblock_kernel_sizes"])
+    for i, (ks, dil) in enumerate(zip(ist["resblock_kernel_sizes"], ist["resblock_dilation_sizes"])):
+        k.resblock_kernel_sizes[i] = ks
+        for j in range(3):
+            k.resblock_dilations[i][j] = dil[j]
+    k.gen_istft_n_fft, k.gen_istft_hop_size = ist["gen_istft_n_fft"], ist["gen_istft_hop_size"]
+    k.compute_dtype = {"float32": _lib.KK_F32, "bfloat16": _lib.KK_BF16}[compute_dtype]
+    return k
+
+
+_NP2KK = {np.dtype(np.float32): _lib.KK_F32, np.dtype(np.float16): _lib.KK_F16}
+
+
+class KokoroEngine:
+    """Owns a finalized kk_model on one GPU and runs batches of utterances through it."""
+
+    def __init__(self, cfg: dict, weights: Dict[str, np.ndarray], compute_dtype: str = "float32", device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise _lib.KokoroHipError("KokoroEngine needs a GPU (torch.cuda.is_available() is False)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.compute_dtype = compute_dtype
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self._h = C.c_void_p()
+        kc = make_kk_config(cfg, compute_dtype)
+        check(self.lib.kk_create(C.byref(kc), C.byref(self._h)), "kk_create")
+        for name, arr in weights.items():
+            self._load(name, arr)
+        with torch.cuda.device(self.device):
+            check(self.lib.kk_finalize(self._h, self._stream()), "kk_finalize")
+        self._ws = None
+        self.upsample = int(np.prod(cfg["istftnet"]["upsample_rates"])) * cfg["istftnet"]["gen_istft_hop_size"] * 2  # samples / frame
+
+    def _load(self, name: str, arr) -> None:
+        if isinstance(arr, torch.Tensor):
+            if arr.dtype == torch.bfloat16:
+                raw = arr.contiguous().view(torch.int16).cpu().numpy()
+                dt = _lib.KK_BF16
+            else:
+                raw = arr.detach().cpu().contiguous().numpy()
+                dt = _NP2KK.get(raw.dtype)
+        else:
+            raw = np.ascontiguousarray(arr)
+            dt = _NP2KK.get(raw.dtype)
+            if dt is None:
+                raw = raw.astype(np.float32)
+                dt = _lib.KK_F32
+        shape = (C.c_int64 * raw.ndim)(*raw.shape)
+        check(self.lib.kk_load_tensor(self._h, name.encode(), dt, shape, raw.ndim, raw.ctypes.data_as(C.c_void_p)), f"kk_load_tensor({name})")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self.lib.kk_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, B: int, Tmax: int, Fmax: int) -> torch.Tensor:
+        n = int(self.lib.kk_workspace_bytes(self._h, B, Tmax, Fmax))
+        if n == 0:
+            raise _lib.KokoroHipError("kk_workspace_bytes returned 0")
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = None
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ batch helpers
+    def pack_ids(self, utterances: Sequence[Sequence[int]]):
+        """[0, ids..., 0] rows (kokoro.py:135), zero padded to the longest."""
+        lens = [len(u) + 2 for u in utterances]
+        Tmax = max(lens)
+        ids = np.zeros((len(utterances), Tmax), np.int32)
+        for b, u in enumerate(utterances):
+            ids[b, 1 : 1 + len(u)] = np.asarray(u, np.int32)
+        return (
+            torch.from_numpy(ids).to(self.device),
+            torch.tensor(lens, dtype=torch.int32, device=self.device),
+            Tmax,
+        )
+
+    def forward(
+        self,
+        ids: torch.Tensor,
+        lens: torch.Tensor,
+        ref_s: torch.Tensor,
+        speed: torch.Tensor,
+        Fmax: int,
+        forced_dur: Optional[torch.Tensor] = None,
+        noise_mode: int = _lib.NOISE_PHILOX,
+        sine_noise: Optional[torch.Tensor] = None,
+        seed: int = 0,
+        out: Optional[torch.Tensor] = None,
+    ):
+        """One kk_forward call on the current stream.  Returns (wav [B, samples_per_frame*Fmax] float32,
+        pred_dur [B, Tmax] int32, nframes [B] int32); nothing is synchronised."""
+        B, Tmax = ids.shape
+        self._last_B = B
+        ws = self.workspace(B, Tmax, Fmax)
+        wav = out if out is not None else torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
+        pred = torch.empty((B, Tmax), dtype=torch.int32, device=self.device)
+        nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(
+            self.lib.kk_forward(
+                self._h, self._stream(), B, Tmax, p(ids), p(lens), p(ref_s), p(speed), p(forced_dur), Fmax, noise_mode, p(sine_noise),
+                C.c_uint64(seed), p(ws), ws.numel(), p(wav), p(pred), p(nfr),
+            ),
+            "kk_forward",
+        )
+        return wav, pred, nfr
+
+    def forward_text(self, ids, lens, ref_s, speed):
+        B, Tmax = ids.shape
+        self._last_B = B
+        ws = self.workspace(B, Tmax, 0)
+        pred = torch.empty((B, Tmax), dtype=torch.int32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self.lib.kk_forward_text(self._h, self._stream(), B, Tmax, p(ids), p(lens), p(ref_s), p(speed), p(ws), ws.numel(), p(pred)),
+              "kk_forward_text")
+        return pred
+
+    def forward_audio(self, B, Tmax, lens, ref_s, dur, Fmax, noise_mode=_lib.NOISE_PHILOX, sine_noise=None, seed=0):
+        # NB: the workspace must be the one kk_forward_text just used (same B, Tmax) and large enough for Fmax
+        need = int(self.lib.kk_workspace_bytes(self._h, B, Tmax, Fmax))
+        if self._ws is None or self._ws.numel() < need:
+            raise _lib.KokoroHipError("forward_audio: call workspace(B, Tmax, Fmax_bound) before forward_text so the text stage's results survive")
+        ws = self._ws
+        self._last_B = B
+        wav = torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
+        nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(
+            self.lib.kk_forward_audio(self._h, self._stream(), B, Tmax, p(lens), p(ref_s), p(dur), Fmax, noise_mode, p(sine_noise),
+                                      C.c_uint64(seed), p(ws), ws.numel(), p(wav), p(nfr)),
+            "kk_forward_audio",
+        )
+        return wav, nfr
+
+    # ------------------------------------------------------------------ debug hooks (tests)
+    def debug_fetch(self, name: str) -> torch.Tensor:
+        rows, ch = C.c_int64(), C.c_int64()
+        check(self.lib.kk_debug_info(self._h, name.encode(), C.byref(rows), C.byref(ch)), "kk_debug_info")
+        B = self._last_B
+        out = torch.empty((B, rows.value, ch.value), dtype=torch.float32, device=self.device)
+        check(self.lib.kk_debug_fetch(self._h, self._stream(), name.encode(), C.c_void_p(out.data_ptr())), "kk_debug_fetch")
+        return out
+
+    def debug_override(self, name: str, t: torch.Tensor) -> None:
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        self._overrides = getattr(self, "_overrides", {})
+        self._overrides[name] = t  # keep alive
+        check(self.lib.kk_debug_override(self._h, name.encode(), C.c_void_p(t.data_ptr())), "kk_debug_override")
+
+    def debug_clear(self) -> None:
+        self.lib.kk_debug_clear(self._h)
+        self._overrides = {}

@@ -556,6 +556,16 @@ class KokoroOracle:
 
     # ---- Model.__call__ (kokoro.py:120-170) ---------------------------------------------------------
 
+    def text_stage(self, input_ids, ref_s, speed: float = 1.0) -> np.ndarray:
+        """kokoro.py:135-150 only: pred_dur [T] int32 (cheap; used by tests to size buffers)."""
+        ids = torch.tensor([[0, *[int(i) for i in input_ids], 0]], dtype=torch.long)
+        ref_s = torch.as_tensor(np.asarray(ref_s, np.float32)).reshape(1, 256).to(self.dtype)
+        d_en = self.linear(self.albert(ids), "bert_encoder").transpose(1, 2)
+        d = self.duration_encoder(d_en, ref_s[:, 128:])
+        x = self.lstm(d, "predictor.lstm")
+        duration = torch.sigmoid(self.linear(x, "predictor.duration_proj.linear_layer")).sum(-1) / speed
+        return torch.clamp(torch.round(duration), min=1).to(torch.int32)[0].numpy()
+
     def forward(
         self,
         input_ids,

@@ -1,0 +1,374 @@
+"""GPU parity tests, kernel level: every HIP kernel family against the CPU oracle / a plain fp32
+PyTorch-CPU statement of the same op, called THROUGH THE C ABI (kk_op_*).
+
+Tolerances are written next to each assertion.  fp32 kernels differ from the oracle only by
+summation order, so relative 1e-5..1e-4 of the tensor's max is the bar; the north-star tolerance
+(1e-3 on the waveform) applies to the end-to-end tests in test_gpu_forward.py.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import kokoro_oracle as O
+from _util import err_stats, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mlx_audio_amd import _lib
+
+    return _lib.load()
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(device="cuda", dtype=dtype).contiguous()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_w(w_oki):
+    """[O][K][I] -> packed [K][I][ldw] (ldw = O rounded up to 64), as kk_finalize does."""
+    O_, K, I = w_oki.shape
+    ldw = (O_ + 63) // 64 * 64
+    p = np.zeros((K, I, ldw), np.float32)
+    p[:, :, :O_] = np.transpose(w_oki, (1, 2, 0))
+    return p, ldw
+
+
+def run_conv(lib, x_nlc, w_oki, bias, *, transposed=False, stride=1, pad=0, dil=1, in_shift=0, in_slope=1.0, act=0, act_slope=0.0,
+             res=None, scale=1.0, accumulate=False, out_init=None, Lout=None, lin=None, lout=None):
+    from mlx_audio_amd import _lib
+
+    B, Lin, Cin = x_nlc.shape
+    O_ = w_oki.shape[0]
+    wp, ldw = pack_w(w_oki)
+    xd, wd = dev(x_nlc), dev(wp)
+    bd = dev(bias) if bias is not None else None
+    out = dev(out_init) if out_init is not None else torch.full((B, Lout, O_), 7.0, device="cuda")
+    rd = dev(res) if res is not None else None
+    lind = dev(np.asarray(lin, np.int32), torch.int32) if lin is not None else None
+    loutd = dev(np.asarray(lout, np.int32), torch.int32) if lout is not None else None
+    rc = lib.kk_op_conv1d(stream(), B, P(xd), Cin, Lin, P(lind), P(wd), ldw, P(bd), Cin, O_, w_oki.shape[1], int(transposed), stride, pad,
+                          dil, in_shift, in_slope, act, act_slope, P(rd), O_, scale, int(accumulate), P(out), O_, Lout, P(loutd),
+                          _lib.KK_F32, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+CONV_CASES = [
+    # name, Cin, Cout, K, stride, pad, dil, L
+    ("k1_linear", 96, 80, 1, 1, 0, 1, 70),
+    ("k3_p1", 50, 70, 3, 1, 1, 1, 200),
+    ("k5_p2", 64, 64, 5, 1, 2, 1, 131),
+    ("k7_d3", 32, 32, 7, 1, 9, 3, 333),
+    ("k11_d5", 16, 24, 11, 1, 25, 5, 400),
+    ("k3_s2_c1", 1, 1, 3, 2, 1, 1, 112),
+    ("k12_s6_c22", 22, 40, 12, 6, 3, 1, 6721),
+    ("k7_c22out", 16, 22, 7, 1, 3, 1, 500),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv1d_generic(lib, case):
+    name, Cin, Cout, K, s, p, d, L = case
+    rng = np.random.default_rng(hash(name) % 2**31)
+    B = 2
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, K, Cin)) / math.sqrt(K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv1d(torch.tensor(x).transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(b), s, p, d).transpose(1, 2).numpy()
+    got = run_conv(lib, x, w, b, stride=s, pad=p, dil=d, Lout=ref.shape[1])
+    e = err_stats(got, ref)
+    report(f"conv1d/{name}", **e)
+    assert e["rel_max"] < 2e-5  # fp32, summation order only
+
+
+def test_conv1d_epilogue_residual_scale_accumulate_gelu_lrelu(lib):
+    rng = np.random.default_rng(3)
+    B, L, Cin, Cout, K = 2, 150, 48, 40, 3
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, K, Cin)) / math.sqrt(K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((B, L, Cout)).astype(np.float32)
+    init = rng.standard_normal((B, L, Cout)).astype(np.float32)
+    xin = np.where(x > 0, x, x * 0.1)
+    base = F.conv1d(torch.tensor(xin).transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(b), 1, 1).transpose(1, 2)
+    ref = ((F.gelu(base) + torch.tensor(res)) * 0.25 + torch.tensor(init)).numpy()
+    got = run_conv(lib, x, w, b, pad=1, in_slope=0.1, act=2, res=res, scale=0.25, accumulate=True, out_init=init, Lout=L)
+    e = err_stats(got, ref)
+    report("conv1d/epilogue_gelu_res_scale_acc", **e)
+    assert e["rel_max"] < 2e-5
+    ref2 = F.leaky_relu(F.conv1d(torch.tensor(x).transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(b), 1, 1), 0.2).transpose(1, 2).numpy()
+    got2 = run_conv(lib, x, w, b, pad=1, act=1, act_slope=0.2, Lout=L)
+    assert err_stats(got2, ref2)["rel_max"] < 2e-5
+
+
+def test_conv1d_ragged_lengths_equal_independent_calls(lib):
+    """Rows past an utterance's length are zero and do not leak into valid rows (== B independent calls)."""
+    rng = np.random.default_rng(4)
+    B, L, C, K, d = 3, 90, 24, 7, 3
+    lens = [90, 37, 5]
+    x = rng.standard_normal((B, L, C)).astype(np.float32)
+    for b, n in enumerate(lens):
+        x[b, n:] = 0  # invariant kept by every producer kernel
+    w = (rng.standard_normal((C, K, C)) / math.sqrt(K * C)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    got = run_conv(lib, x, w, bias, pad=9, dil=d, Lout=L, lin=lens, lout=lens)
+    for b, n in enumerate(lens):
+        ref = F.conv1d(torch.tensor(x[b : b + 1, :n]).transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 9, d).transpose(1, 2).numpy()[0]
+        assert err_stats(got[b, :n], ref)["rel_max"] < 2e-5
+        assert np.all(got[b, n:] == 0)
+
+
+@pytest.mark.parametrize("cfg", [(20, 10, 5, 64, 32, 28), (12, 6, 3, 32, 16, 100), (3, 2, 1, 8, 8, 33)], ids=["ups0", "ups1", "k3s2"])
+def test_conv_transpose1d(lib, cfg):
+    K, s, p, Cin, Cout, L = cfg
+    rng = np.random.default_rng(K)
+    B = 2
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    w_iko = (rng.standard_normal((Cin, K, Cout)) / math.sqrt(K * Cin / s)).astype(np.float32)  # weight_v layout of Generator.ups
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv_transpose1d(torch.tensor(x).transpose(1, 2), torch.tensor(w_iko).permute(0, 2, 1), torch.tensor(b), s, p).transpose(1, 2).numpy()
+    w_oki = np.transpose(w_iko, (2, 1, 0))  # packed form is [K][Cin][Cout] either way
+    got = run_conv(lib, x, w_oki, b, transposed=True, stride=s, pad=p, Lout=ref.shape[1])
+    e = err_stats(got, ref)
+    report(f"convT/k{K}s{s}", **e)
+    assert e["rel_max"] < 2e-5
+
+
+def test_conv1x1_with_nearest_upsampled_input(lib):
+    rng = np.random.default_rng(9)
+    B, L, Cin, Cout = 2, 41, 30, 20
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    w = rng.standard_normal((Cout, 1, Cin)).astype(np.float32)
+    xu = np.repeat(x, 2, axis=1)
+    ref = np.einsum("blc,oc->blo", xu, w[:, 0, :])
+    got = run_conv(lib, x, w, None, in_shift=1, Lout=2 * L)
+    assert err_stats(got, ref)["rel_max"] < 2e-5
+
+
+def _oracle_stub(weights=None):
+    import mlx_audio_amd.params as Pm
+
+    cfg = Pm.tiny_config()
+    return O.KokoroOracle(weights or {}, cfg)
+
+
+@pytest.mark.parametrize("act", ["snake", "lrelu", "lrelu_pool"])
+def test_adain_act(lib, act):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(11)
+    B, L, C = 2, 700, 50
+    lens = [700, 333]
+    x = (rng.standard_normal((B, L, C)) * 2 + 3).astype(np.float32)
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    gb = (rng.standard_normal((B, 2 * C)) * 0.5).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    pw = rng.standard_normal((C, 3)).astype(np.float32)
+    pb = rng.standard_normal(C).astype(np.float32)
+    pool = act.endswith("pool")
+    Lout = 2 * L if pool else L
+    Cpad = 64
+    out = torch.full((B, Lout, Cpad), 5.0, device="cuda")
+    scratch = torch.empty(B * ((L + 511) // 512) * 2 * C + 2 * B * C + 64, device="cuda")
+    xd, gbd, ald, pwd, pbd = dev(x), dev(gb), dev(alpha), dev(pw), dev(pb)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_adain(stream(), B, P(xd), C, L, P(lend), C, P(gbd), 2 * C, _lib.ACT_SNAKE if act == "snake" else _lib.ACT_LRELU, 0.2,
+                         P(ald), int(pool), P(pwd), P(pbd), P(out), Cpad, Cpad, Lout, P(scratch), scratch.numel(), _lib.KK_F32, 0)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b, n in enumerate(lens):
+        xb = torch.tensor(x[b : b + 1, :n]).transpose(1, 2)  # [1,C,n]
+        mean = xb.mean(-1, keepdim=True)
+        var = ((xb - mean) ** 2).mean(-1, keepdim=True)
+        xn = (xb - mean) / torch.sqrt(var + 1e-5)
+        y = (1 + torch.tensor(gb[b, :C])[None, :, None]) * xn + torch.tensor(gb[b, C:])[None, :, None]
+        if act == "snake":
+            a = torch.tensor(alpha)[None, :, None]
+            y = y + (1 / a) * torch.sin(a * y) ** 2
+        else:
+            y = torch.where(y > 0, y, 0.2 * y)
+        if pool:
+            y = F.conv_transpose1d(y, torch.tensor(pw)[:, None, :], torch.tensor(pb), 2, 1, 0, C)
+            y = F.pad(y, (1, 0))
+        ref = y.transpose(1, 2).numpy()[0]
+        no = 2 * n if pool else n
+        e = err_stats(got[b, :no, :C], ref)
+        report(f"adain/{act}/b{b}", **e)
+        assert e["rel_max"] < 1e-5
+        assert np.all(got[b, no:] == 0) and np.all(got[b, :, C:] == 0)
+
+
+def test_layernorm_and_adaln(lib):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(12)
+    B, L = 2, 37
+    for C in (128, 512, 768):
+        x = rng.standard_normal((B, L, C)).astype(np.float32) * 3 + 1
+        r = rng.standard_normal((B, L, C)).astype(np.float32)
+        w = rng.standard_normal(C).astype(np.float32)
+        b = rng.standard_normal(C).astype(np.float32)
+        out = torch.empty((B, L, C), device="cuda")
+        xd, rd, wd, bd = dev(x), dev(r), dev(w), dev(b)
+        rc = lib.kk_op_layernorm(stream(), B, P(xd), C, P(rd), C, L, None, C, P(wd), P(bd), None, 0, 1e-12, 0, 0.0, P(out), C, _lib.KK_F32)
+        assert rc == 0, lib.kk_last_error()
+        ref = F.layer_norm(torch.tensor(x + r), (C,), torch.tensor(w), torch.tensor(b), 1e-12).numpy()
+        torch.cuda.synchronize()
+        e = err_stats(out.cpu().numpy(), ref)
+        report(f"layernorm/C{C}", **e)
+        assert e["rel_max"] < 1e-5
+    C = 64
+    x = rng.standard_normal((B, L, C)).astype(np.float32)
+    gb = rng.standard_normal((B, 2 * C)).astype(np.float32)
+    out = torch.empty((B, L, C), device="cuda")
+    xd, gd = dev(x), dev(gb)
+    rc = lib.kk_op_layernorm(stream(), B, P(xd), C, None, 0, L, None, C, None, None, P(gd), 2 * C, 1e-5, 0, 0.0, P(out), C, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    xn = F.layer_norm(torch.tensor(x), (C,), None, None, 1e-5)
+    ref = ((1 + torch.tensor(gb[:, None, :C])) * xn + torch.tensor(gb[:, None, C:])).numpy()
+    torch.cuda.synchronize()
+    assert err_stats(out.cpu().numpy(), ref)["rel_max"] < 1e-5
+
+
+@pytest.mark.parametrize("H,I,L", [(32, 48, 21), (256, 640, 40)])
+def test_lstm_bidirectional(lib, H, I, L):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(H)
+    B = 2
+    lens = [L, max(1, L // 3)]
+    s = 1.0 / math.sqrt(H)
+    w = {}
+    for d in ("forward", "backward"):
+        w[f"l.Wx_{d}"] = rng.uniform(-s, s, (4 * H, I)).astype(np.float32)
+        w[f"l.Wh_{d}"] = rng.uniform(-s, s, (4 * H, H)).astype(np.float32)
+        w[f"l.bias_ih_{d}"] = rng.uniform(-s, s, 4 * H).astype(np.float32)
+        w[f"l.bias_hh_{d}"] = rng.uniform(-s, s, 4 * H).astype(np.float32)
+    orc = _oracle_stub(w)
+    x = rng.standard_normal((B, L, I)).astype(np.float32)
+    xproj = np.zeros((B, L, 2, 4 * H), np.float32)
+    whT = np.zeros((2, H, 4 * H), np.float32)
+    for di, d in enumerate(("forward", "backward")):
+        xproj[:, :, di] = (w[f"l.bias_ih_{d}"] + w[f"l.bias_hh_{d}"]) + x @ w[f"l.Wx_{d}"].T
+        whT[di] = w[f"l.Wh_{d}"].T
+    out = torch.full((B, L, 2 * H), 3.0, device="cuda")
+    xp, wt = dev(xproj), dev(whT)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_lstm(stream(), B, P(xp), P(wt), H, L, P(lend), P(out), 2 * H, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b, n in enumerate(lens):
+        ref = orc.lstm(torch.tensor(x[b : b + 1, :n]), "l").numpy()[0]
+        e = err_stats(got[b, :n], ref)
+        report(f"lstm/H{H}/b{b}", **e)
+        assert e["max_abs"] < 2e-5  # outputs are in (-1, 1)
+        assert np.all(got[b, n:] == 0)
+
+
+def test_attention(lib):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(21)
+    B, T, heads = 2, 130, 3
+    hs = heads * 64
+    lens = [130, 77]
+    qkv = rng.standard_normal((B, T, 3 * hs)).astype(np.float32)
+    out = torch.full((B, T, hs), 9.0, device="cuda")
+    qd = dev(qkv)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_attention(stream(), B, P(qd), 3 * hs, T, P(lend), heads, P(out), hs, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b, n in enumerate(lens):
+        t = torch.tensor(qkv[b, :n])
+        q, k, v = [t[:, i * hs : (i + 1) * hs].view(n, heads, 64).permute(1, 0, 2) for i in range(3)]
+        pr = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+        ref = (pr @ v).permute(1, 0, 2).reshape(n, hs).numpy()
+        e = err_stats(got[b, :n], ref)
+        report(f"attention/b{b}", **e)
+        assert e["rel_max"] < 1e-5
+        assert np.all(got[b, n:] == 0)
+
+
+def test_source_and_stft(lib):
+    """SineGen + SourceModuleHnNSF + STFT(20) against the oracle with INJECTED noise.  The phase channels are
+    compared where the bin magnitude is not tiny (the angle of a ~1e-7 bin is noise in any implementation)."""
+    from mlx_audio_amd import _lib
+    import mlx_audio_amd.params as Pm
+
+    rng = np.random.default_rng(5)
+    cfg = Pm.tiny_config()
+    lw = rng.standard_normal((1, 9)).astype(np.float32) * 0.7
+    lb = np.array([0.05], np.float32)
+    orc = O.KokoroOracle({"decoder.generator.m_source.l_linear.weight": lw, "decoder.generator.m_source.l_linear.bias": lb}, cfg)
+    B, L2 = 2, 48
+    f0 = (rng.standard_normal((B, L2)) * 80 + 120).astype(np.float32)
+    f0[0, 5:9] = -3.0  # unvoiced stretch
+    noise = rng.standard_normal((B, 300 * L2, 9)).astype(np.float32)
+    Tf = 60 * L2 + 1
+    phase = torch.empty((B, 9, L2), device="cuda")
+    hs = torch.empty((B, 300 * L2), device="cuda")
+    har = torch.empty((B, Tf, 22), device="cuda")
+    fd, ld_, nd = dev(f0), dev(lw[0]), dev(noise)
+    rc = lib.kk_op_source_stft(stream(), B, P(fd), L2, None, P(ld_), float(lb[0]), _lib.NOISE_INJECTED, P(nd), C.c_uint64(0), P(phase), P(hs),
+                               P(har), 22, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    for b in range(B):
+        har_ref, hs_ref = orc.har_features(f0[b : b + 1], None, noise[b : b + 1])
+        e = err_stats(hs.cpu().numpy()[b], hs_ref[0])
+        report(f"source/har_source/b{b}", **e)
+        # phase accumulators reach 1e4 rad in float32: sin() arguments agree to a few ulp -> ~1e-3 abs is the honest bar
+        assert e["max_abs"] < 5e-3 and e["rms_rel"] < 2e-3
+        got = har.cpu().numpy()[b]  # [Tf, 22]
+        mag_ref, ph_ref = har_ref[0, :11].T, har_ref[0, 11:].T
+        em = err_stats(got[:, :11], mag_ref)
+        report(f"source/stft_mag/b{b}", **em)
+        assert em["max_abs"] < 5e-3
+        strong = mag_ref > 1e-2
+        dphi = np.angle(np.exp(1j * (got[:, 11:] - ph_ref)))
+        report(f"source/stft_phase/b{b}", max_abs=float(np.abs(dphi[strong]).max()), frac_strong=float(strong.mean()))
+        assert np.abs(dphi[strong]).max() < 0.5
+
+
+def test_istft_head(lib):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(7)
+    B, Tf = 3, 481
+    lens = [481, 121, 1]
+    x = (rng.standard_normal((B, Tf, 22)) * 1.5).astype(np.float32)
+    orc = _oracle_stub()
+    wav = torch.full((B, 5 * (Tf - 1)), 4.0, device="cuda")
+    xd = dev(x)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_istft_head(stream(), B, P(xd), 22, Tf, P(lend), P(wav), _lib.KK_F32, 0)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = wav.cpu().numpy()
+    for b, n in enumerate(lens):
+        if n > 1:
+            ref = orc.istft_head(np.transpose(x[b : b + 1, :n], (0, 2, 1)))[0, 0]
+            e = err_stats(got[b, : 5 * (n - 1)], ref)
+            report(f"istft_head/b{b}", **e)
+            assert e["rel_max"] < 2e-5
+        assert np.all(got[b, 5 * (n - 1) :] == 0)
