@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per wall-second (xRT), Kokoro-82M, batch = 32 fixed 128-phoneme
+utterances per GPU (BASELINE.json configs[1]); utterances are sharded over ranks (weak scaling) and the
+waveforms are gathered to rank 0 with one RCCL gather per step.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one kk_forward over one batch (the whole acoustic path incl. duration prediction; the durations that
+are REALISED are pinned to 5 frames per token so every rank does identical work: T = 130, F = 650,
+390 000 samples = 16.25 s per utterance).  Inputs (ids, style rows, weights) are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT,):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+N_PHONEMES = 128
+FRAMES_PER_TOKEN = 5
+BATCH_PER_GPU = 32
+SR = 24000
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense; never the 2:1 sparse marketing numbers)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, w, utt, ref_s):
+    """The CPU oracle (kind "port": our restatement of the reference's algorithm) on the host cores of this
+    box, on a bounded sample of the same workload: ONE config-2 utterance (T = 130, F = 650, 16.25 s audio)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kokoro_oracle as O
+
+    orc = O.KokoroOracle(w, cfg)
+    cores = torch.get_num_threads()
+    dur = np.full(N_PHONEMES + 2, FRAMES_PER_TOKEN, np.int32)
+    noise = np.random.default_rng(0).standard_normal((1, 600 * int(dur.sum()), 9)).astype(np.float32)
+    t0 = time.time()
+    a, _ = orc.forward(utt, ref_s, 1.0, forced_dur=dur, sine_noise=noise)
+    dt = time.time() - t0
+    return {"value": (a.shape[0] / SR) / dt, "unit": "audio-sec/sec", "cores": int(cores), "kind": "port",
+            "sample": f"1 utterance of the same workload (T=130, F=650, 16.25 s audio) in {dt:.1f} s; oracle/kokoro_oracle.py, torch-CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default=os.environ.get("KK_BENCH_DTYPE", "float32"), choices=["float32", "bfloat16"])
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import mlx_audio_amd.params as P
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.engine import KokoroEngine
+    from mlx_audio_amd.parallel import gather_waveforms, shard_range
+
+    cfg = P.kokoro_config()
+    w = P.synth_checkpoint(cfg, 0)
+    if args.dtype == "bfloat16":
+        w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
+    eng = KokoroEngine(cfg, w, compute_dtype=args.dtype)
+    dev = eng.device
+
+    # ---- synthetic workload: global batch = world * B utterances, this rank takes its contiguous shard
+    B = args.batch
+    Bglob = B * world
+    rng = np.random.default_rng(0)
+    all_utts = [rng.integers(1, 178, N_PHONEMES).tolist() for _ in range(Bglob)]
+    rows = np.load(os.path.join(ROOT, "tests", "golden", "af_heart_rows.npz"))["rows"]
+    all_ref = rows[rng.integers(0, rows.shape[0], Bglob)].astype(np.float32)
+    lo, hi = shard_range(Bglob, world, rank)
+    utts, ref_np = all_utts[lo:hi], all_ref[lo:hi]
+    ids, lens, Tmax = eng.pack_ids(utts)
+    ref_s = torch.tensor(ref_np, device=dev)
+    speed = torch.ones(B, device=dev)
+    forced = torch.full((B, Tmax), FRAMES_PER_TOKEN, dtype=torch.int32, device=dev)
+    Fmax = FRAMES_PER_TOKEN * Tmax
+    wav = torch.empty((B, 600 * Fmax), dtype=torch.float32, device=dev)
+    gathered = torch.empty((Bglob, 600 * Fmax), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    eng.workspace(B, Tmax, Fmax)
+
+    def step(i):
+        eng.forward(ids, lens, ref_s, speed, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=1000 + i, out=wav)
+        if world > 1:
+            gather_waveforms(wav, gathered, dist)  # one exchange step: every shard's waveforms land on rank 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    if not args.no_profile:
+        eng.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end() if not args.no_profile else None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    audio_s = Bglob * (600 * Fmax) / SR * args.steps
+    dtype_tag = "bf16" if args.dtype == "bfloat16" else "f32"
+    out = {
+        "metric": "audio-sec/sec (xRT), Kokoro-82M batch=32 fixed 128-phoneme utterances per GPU",
+        "value": audio_s / dt,
+        "unit": "audio-sec/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype_tag,
+        "data": "synthetic (seeded random-init checkpoint of the Kokoro-82M architecture, random phoneme ids, real af_heart style rows, Philox noise)",
+        "config": {"workload": f"Kokoro-82M {dtype_tag}, batch={B}/GPU fixed {N_PHONEMES}-phoneme utterances (T={Tmax}, F={Fmax}, {600 * Fmax} samples = "
+                               f"{600 * Fmax / SR:.2f} s each), utterance-sharded over {world} GPU(s)" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                   "global_batch": Bglob, "parallelism": f"utterance-shard x{world}"},
+    }
+    if rank == 0:
+        if prof is not None:
+            # dominant kernel = the convolution family (carries ~99 % of the algorithmic FLOPs)
+            conv = prof["conv_mfma"] if prof["conv_mfma"]["ms"] > prof["conv_generic"]["ms"] else prof["conv_generic"]
+            peak = PEAK_TFLOPS["bf16" if conv is prof["conv_mfma"] else "f32"]
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma" if conv is prof["conv_mfma"] else "conv_generic (fp32 VALU implicit GEMM)",
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "launches_per_step": conv["launches"] / args.steps, "ms_per_step": conv["ms"] / args.steps}
+            ih = prof["istft_head"]
+            if ih["ms"] > 0:
+                gbs = ih["bytes"] / (ih["ms"] * 1e-3) / 1e9
+                out["roofline_istft_head"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                              "traffic": None, "us_per_launch": ih["ms"] / ih["launches"] * 1e3}
+            tot = sum(v["ms"] for v in prof.values())
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+            out["kernel_ms_per_step"]["_sum_bracketed"] = round(tot / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, P.synth_checkpoint(cfg, 0), utts[0], ref_np[0:1])
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,12 @@ int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
 int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
 void kk_debug_clear(kk_model* m);
 
+/* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
+ * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention
+ *          8 source 9 stft.  kk_profile_end returns summed milliseconds, algorithmic flops / bytes and launch counts. */
+int kk_profile_begin(kk_model* m, int max_launches);
+int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

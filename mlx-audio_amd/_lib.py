@@ -51,6 +51,8 @@ SIGNATURES = {
     "kk_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_override": (_i, [_vp, C.c_char_p, _vp]),
     "kk_debug_clear": (None, [_vp]),
+    "kk_profile_begin": (_i, [_vp, _i]),
+    "kk_profile_end": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

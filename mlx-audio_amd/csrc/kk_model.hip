@@ -129,6 +129,12 @@ struct kk_model {
 
   std::map<std::string, DebugEntry> dbg;
   std::map<std::string, const float*> dbg_over;
+
+  // optional per-kernel-class timing (kk_profile_*): HIP events around every launch of a class
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;  // pairs
+  struct ProfRec { int cls; double flops; double bytes; };
+  std::vector<ProfRec> prof_rec;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +160,7 @@ extern "C" int kk_create(const kk_config* cfg, kk_model** out) {
 extern "C" void kk_destroy(kk_model* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
+  for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m;
 }
 
@@ -652,6 +659,22 @@ struct Ctx {
   float* f32(size_t n) { return (float*)raw(n * 4); }
   int* i32(size_t n) { return (int*)raw(n * 4); }
 
+  // ---- profiling: bracket a launch with events (only when kk_profile_begin was called)
+  void prof_start() {
+    if (dry || !m->prof_on) return;
+    const size_t i = m->prof_rec.size();
+    if (2 * i + 1 >= m->prof_ev.size()) return;
+    (void)hipEventRecord(m->prof_ev[2 * i], st);
+  }
+  void prof_stop(int cls, double flops, double bytes) {
+    if (dry || !m->prof_on) return;
+    const size_t i = m->prof_rec.size();
+    if (2 * i + 1 >= m->prof_ev.size()) return;
+    (void)hipEventRecord(m->prof_ev[2 * i + 1], st);
+    m->prof_rec.push_back({cls, flops, bytes});
+  }
+  static double esz(int dt) { return dt == KK_F32 ? 4.0 : 2.0; }
+
   int dbg(const char* name, const Buf& b, int C) {
     if (dry) return 0;
     auto it = m->dbg_over.find(name);
@@ -674,7 +697,16 @@ struct Ctx {
     a.Q = Q; a.Lo_rows = out.rows;
     a.lin = lin; a.lout = lout;
     a.in_slope = o.in_slope; a.scale = o.scale; a.accumulate = o.accumulate; a.act = o.act; a.act_slope = o.act_slope;
-    return kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
+    // algorithmic work of this launch at full length: every output row sums Kw*Cin (conv) or Kw/stride*Cin (convT) products
+    const double rows_out = o.mode == KK_CONVT ? (double)Q * o.stride : (double)Q;
+    const double taps = o.mode == KK_CONVT ? (double)w.Kw / o.stride : (double)w.Kw;
+    const double flops = 2.0 * B * rows_out * w.Cout * w.Cin * taps;
+    const double bytes = B * (rows_out * w.Cout * esz(out.dtype) * (o.res ? 2.0 : 1.0) + (double)Q * (o.mode == KK_CONVT ? 1 : o.stride) * w.Cin * esz(x.dtype)) +
+                         (double)w.Kw * w.Cin * w.Cout * 4.0;
+    prof_start();
+    const int rc = kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
+    prof_stop(0, flops, bytes);
+    return rc;
   }
 
   // scratch for instance-norm statistics, sized for the largest request seen in the dry run
@@ -689,7 +721,10 @@ struct Ctx {
     memset(&a, 0, sizeof a);
     a.x = x.p; a.xbs = x.bs; a.ldx = x.ld; a.C = C; a.Lmax = Lmax; a.len = len;
     a.partial = st_partial; a.rows_per_chunk = ROWS_PER_CHUNK; a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
-    return kk_launch_instnorm_stats(a, B, x.dtype, st);
+    prof_start();
+    const int rc = kk_launch_instnorm_stats(a, B, x.dtype, st);
+    prof_stop(2, 3.0 * B * Lmax * C, (double)B * Lmax * C * esz(x.dtype));
+    return rc;
   }
   int adain(const Buf& x, int C, KKLen len_in, const Buf& out, int Cpad, int Lmax_out, const float* gb, int gbs, int act, float slope,
             const float* alpha, int pool, const float* pool_w, const float* pool_b) {
@@ -700,7 +735,10 @@ struct Ctx {
     a.C = C; a.Cpad = Cpad; a.Lmax_out = Lmax_out; a.len_in = len_in;
     a.mean = st_mean; a.rstd = st_rstd; a.gb = gb; a.gbs = gbs; a.act = act; a.slope = slope; a.alpha = alpha;
     a.pool = pool; a.pool_w = pool_w; a.pool_b = pool_b; a.fast = adt == KK_BF16;
-    return kk_launch_adain_act(a, B, x.dtype, st);
+    prof_start();
+    const int rc = kk_launch_adain_act(a, B, x.dtype, st);
+    prof_stop(3, 8.0 * B * Lmax_out * C, (double)B * Lmax_out * C * esz(x.dtype) * (pool ? 1.5 : 2.0));
+    return rc;
   }
   int layernorm(const Buf& x, const Buf* res, const Buf& out, int C, int Lmax, KKLen len, const float* w, const float* b, const float* gb,
                 int gbs, float eps, int act, float slope) {
@@ -711,7 +749,10 @@ struct Ctx {
     if (res) { a.res = res->p; a.rbs = res->bs; a.ldr = res->ld; }
     a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.C = C; a.Lmax = Lmax; a.len = len; a.w = w; a.bias = b; a.gb = gb; a.gbs = gbs;
     a.eps = eps; a.act = act; a.slope = slope;
-    return kk_launch_layernorm(a, B, x.dtype, st);
+    prof_start();
+    const int rc = kk_launch_layernorm(a, B, x.dtype, st);
+    prof_stop(6, 8.0 * B * Lmax * C, (double)B * Lmax * C * esz(x.dtype) * (res ? 3.0 : 2.0));
+    return rc;
   }
   int lstm(const LstmW& l, const Buf& x, int Cin_ld_unused, float* xproj, const Buf& out, int Lmax, KKLen len) {
     (void)Cin_ld_unused;
@@ -723,7 +764,10 @@ struct Ctx {
     KKLstmArgs a;
     memset(&a, 0, sizeof a);
     a.xproj = xproj; a.whT = l.whT.p; a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.H = l.H; a.Lmax = Lmax; a.len = len;
-    return kk_launch_lstm(a, B, out.dtype, st);
+    prof_start();
+    const int rc = kk_launch_lstm(a, B, out.dtype, st);
+    prof_stop(4, 2.0 * B * Lmax * 2 * 4 * l.H * l.H, 2.0 * Lmax * 4 * l.H * l.H * 4.0 * B);
+    return rc;
   }
 };
 
@@ -815,7 +859,9 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
       memset(&aa, 0, sizeof aa);
       aa.qkv = qkv.p; aa.bs = qkv.bs; aa.ld = qkv.ld; aa.out = ctxb.p; aa.obs = ctxb.bs; aa.ldo = ctxb.ld;
       aa.heads = cf.plbert_heads; aa.hs = hs; aa.Tmax = Tmax; aa.len = lT; aa.scale = 0.125f;
+      c.prof_start();
       KK_TRY(kk_launch_attention(aa, B, qkv.dtype, c.st));
+      c.prof_stop(7, 4.0 * B * cf.plbert_heads * (double)Tmax * Tmax * 64, (double)B * Tmax * 4 * hs * Ctx::esz(qkv.dtype));
     }
     KK_TRY(c.conv(m->att_dense, ctxb, lT, tmp, lT, Tmax, plain));
     KK_TRY(c.layernorm(tmp, &x, att, hs, Tmax, lT, m->att_ln_w.p, m->att_ln_b.p, nullptr, 0, 1e-12f, KK_ACT_NONE, 0.f));
@@ -972,11 +1018,15 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     memset(&sa, 0, sizeof sa);
     sa.f0 = (const float*)f0n[0].p; sa.L2max = L2; sa.len2 = lens4; sa.phase = phase; sa.lin_w = m->lin_w.p; sa.lin_b = m->lin_b;
     sa.noise = noise; sa.seed = seed; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
+    c.prof_start();
     KK_TRY(kk_launch_source(sa, B, c.st));
+    c.prof_stop(8, 0.0, (double)B * Nw * 4.0);
     Buf hsb;
     hsb.p = har_source; hsb.ld = 1; hsb.bs = Nw; hsb.rows = Nw; hsb.dtype = KK_F32;
     KK_TRY(c.dbg("har_source", hsb, 1));
+    c.prof_start();
     KK_TRY(kk_launch_stft20(har_source, Nw, lens4 + 3 * B, har.p, har.bs, har.ld, Tf, B, har.dtype, c.st));
+    c.prof_stop(9, 880.0 * B * Tf, (double)B * (Nw * 4.0 + Tf * 22.0 * Ctx::esz(har.dtype)));
   }
   KK_TRY(c.dbg("har", har, 22));
   // ---- up-sampling stages (istftnet.py:776-796)
@@ -1031,8 +1081,12 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   op.in_slope = 0.01f;
   KK_TRY(c.conv(m->conv_post, cur, lTf, cp, lTf, Tf, op));
   KK_TRY(c.dbg("conv_post", cp, 22));
-  if (!c.dry)
+  if (!c.dry) {
+    c.prof_start();
     KK_TRY(kk_launch_istft_head(cp.p, cp.bs, cp.ld, lens4 + 2 * B, Tf, wav_out, (long long)Nw, B, cp.dtype, c.adt == KK_BF16 ? 1 : 0, c.st));
+    // algorithmic bytes: 22 inputs per frame column + 5 fp32 samples per frame column
+    c.prof_stop(5, 800.0 * B * Tf, (double)B * Tf * (22.0 * Ctx::esz(cp.dtype) + 20.0));
+  }
   return 0;
 }
 
@@ -1219,4 +1273,36 @@ extern "C" void kk_debug_clear(kk_model* m) {
   if (!m) return;
   m->dbg_over.clear();
   m->dbg.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel-class timing (bench.py / profiling only)
+// ------------------------------------------------------------------------------------------------
+extern "C" int kk_profile_begin(kk_model* m, int max_launches) {
+  if (!m || max_launches <= 0) return kk_fail("kk_profile_begin: bad argument");
+  while ((int)m->prof_ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return kk_fail("kk_profile_begin: hipEventCreate failed");
+    m->prof_ev.push_back(e);
+  }
+  m->prof_rec.clear();
+  m->prof_on = true;
+  return 0;
+}
+// Sums the recorded launches per class: ms[cls], flops[cls], bytes[cls], count[cls] for cls < ncls.  Synchronises the
+// events it reads.  Classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm
+// 7 attention 8 source 9 stft
+extern "C" int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count) {
+  if (!m || !ms || !flops || !bytes || !count) return kk_fail("kk_profile_end: null argument");
+  for (int i = 0; i < ncls; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; count[i] = 0; }
+  m->prof_on = false;
+  for (size_t i = 0; i < m->prof_rec.size(); ++i) {
+    if (hipEventSynchronize(m->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, m->prof_ev[2 * i], m->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: elapsed failed");
+    const auto& r = m->prof_rec[i];
+    if (r.cls >= 0 && r.cls < ncls) { ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; count[r.cls] += 1; }
+  }
+  m->prof_rec.clear();
+  return 0;
 }

@@ -167,6 +167,19 @@ class KokoroEngine:
         )
         return wav, nfr
 
+    # ------------------------------------------------------------------ per-kernel-class timing (bench)
+    PROFILE_CLASSES = ["conv_generic", "conv_mfma", "instnorm_stats", "adain_act", "lstm", "istft_head", "layernorm", "attention",
+                       "source", "stft"]
+
+    def profile_begin(self, max_launches: int = 200000) -> None:
+        check(self.lib.kk_profile_begin(self._h, max_launches), "kk_profile_begin")
+
+    def profile_end(self) -> dict:
+        n = len(self.PROFILE_CLASSES)
+        ms, fl, by, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+        check(self.lib.kk_profile_end(self._h, n, ms, fl, by, cnt), "kk_profile_end")
+        return {k: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": cnt[i]} for i, k in enumerate(self.PROFILE_CLASSES)}
+
     # ------------------------------------------------------------------ debug hooks (tests)
     def debug_fetch(self, name: str) -> torch.Tensor:
         rows, ch = C.c_int64(), C.c_int64()

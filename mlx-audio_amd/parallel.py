@@ -1,0 +1,69 @@
+"""Utterance sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is
+RCCL on ROCm).  The path has exactly one exchange step: the finished waveforms travel to rank 0.  Utterances
+(text chunks, pipeline.py:199-226) are independent, the 82M-parameter model is replicated, so there is no
+other collective anywhere in the forward."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [lo, hi) of n_items for `rank` (first n_items % world ranks get one more)."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def balanced_assignment(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of utterances (cost ~ predicted frames) to ranks."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: loads[k])
+        out[r].append(i)
+        loads[r] += costs[i]
+    return out
+
+
+def gather_waveforms(local: torch.Tensor, out_root: Optional[torch.Tensor], dist, dst: int = 0) -> None:
+    """Equal-shape gather: rank r's [B, N] block lands in out_root[r*B:(r+1)*B] on `dst`.  With RCCL this is one
+    grouped send/recv: every peer writes to the root over its own xGMI link (no ring)."""
+    world = dist.get_world_size()
+    if dist.get_rank() == dst:
+        B = local.shape[0]
+        chunks = [out_root[r * B : (r + 1) * B] for r in range(world)]
+        dist.gather(local, gather_list=chunks, dst=dst)
+    else:
+        dist.gather(local, gather_list=None, dst=dst)
+
+
+def gather_ragged(local: torch.Tensor, nsamples: torch.Tensor, dist, dst: int = 0):
+    """Variable-length gather (RCCL has no gatherv): all_gather the per-utterance sample counts, then every rank
+    sends its [B, Nmax_local] block trimmed to its own longest utterance.  Returns (list of 1-D waveforms in global
+    order) on `dst`, None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    B = local.shape[0]
+    counts = [torch.empty_like(nsamples) for _ in range(world)]
+    dist.all_gather(counts, nsamples)
+    widths = [int(c.max().item()) if c.numel() else 0 for c in counts]
+    if rank == dst:
+        bufs = [torch.empty((B, widths[r]), dtype=local.dtype, device=local.device) for r in range(world)]
+        reqs = []
+        for r in range(world):
+            if r == dst:
+                bufs[r].copy_(local[:, : widths[r]])
+            elif widths[r] > 0:
+                reqs.append(dist.irecv(bufs[r], src=r))
+        for q in reqs:
+            q.wait()
+        out = []
+        for r in range(world):
+            for b in range(B):
+                out.append(bufs[r][b, : int(counts[r][b].item())])
+        return out
+    if widths[rank] > 0:
+        dist.send(local[:, : widths[rank]].contiguous(), dst=dst)
+    return None

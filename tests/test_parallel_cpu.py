@@ -1,0 +1,83 @@
+"""Multi-process (gloo, world_size 2) tests of the utterance-shard + gather path; runs on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mlx_audio_amd import parallel as par
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                lo, hi = par.shard_range(n, world, r)
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+            sizes = [par.shard_range(n, world, r)[1] - par.shard_range(n, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_balanced_assignment():
+    costs = [650, 10, 640, 20, 300, 310, 5, 5]
+    a = par.balanced_assignment(costs, 2)
+    assert sorted(a[0] + a[1]) == list(range(8))
+    loads = [sum(costs[i] for i in g) for g in a]
+    assert abs(loads[0] - loads[1]) <= 30
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, N = 3, 50
+        local = torch.arange(B * N, dtype=torch.float32).reshape(B, N) + 1000 * rank
+        out = torch.zeros((world * B, N)) if rank == 0 else None
+        par.gather_waveforms(local, out, dist)
+        ok = True
+        if rank == 0:
+            for r in range(world):
+                ok &= bool(torch.equal(out[r * B : (r + 1) * B], torch.arange(B * N, dtype=torch.float32).reshape(B, N) + 1000 * r))
+        # ragged
+        ns = torch.tensor([10 + rank, 50, 3 * (rank + 1)], dtype=torch.int32)
+        rag = par.gather_ragged(local, ns, dist)
+        if rank == 0:
+            ok &= len(rag) == world * B
+            for r in range(world):
+                for b in range(B):
+                    n = [10 + r, 50, 3 * (r + 1)][b]
+                    exp = (torch.arange(B * N, dtype=torch.float32).reshape(B, N) + 1000 * r)[b, :n]
+                    ok &= bool(torch.equal(rag[r * B + b], exp))
+        else:
+            ok &= rag is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
