@@ -575,6 +575,7 @@ class KokoroOracle:
         rand_ini=None,
         sine_noise=None,
         return_inter: bool = False,
+        f0n_override=None,
     ):
         """input_ids: python list of token ids WITHOUT the BOS/EOS zeros (kokoro.py:135 adds them).
         ref_s [1, 256].  Returns (audio [600F] float32, pred_dur [T] int32[, inter])."""
@@ -603,6 +604,9 @@ class KokoroOracle:
         aln[idx, torch.arange(Fr)] = 1
         en = d.transpose(1, 2) @ aln[None]  # [1,640,F]
         F0_pred, N_pred = self.f0n_train(en, s)
+        if f0n_override is not None:  # tests: condition the vocoder on given F0 / N curves (see DESIGN.md "conditioning")
+            F0_pred = torch.as_tensor(np.asarray(f0n_override[0], np.float32)).reshape(1, -1).to(dt)
+            N_pred = torch.as_tensor(np.asarray(f0n_override[1], np.float32)).reshape(1, -1).to(dt)
         t_en = self.text_encoder(ids)
         asr = t_en @ aln[None]
         if inter is not None:

@@ -6,9 +6,11 @@
                               golden INPUTS (pipeline.py:236 picks row len(ps)-1).
   tiny_case.npz               ids / style row / speed / noise seed of one tiny-config utterance with the ORACLE's
                               waveform, durations and F0 curve (what the HIP path must reproduce).
-  config2_oracle_digest.json  max|.| and std of the oracle waveform for the two BASELINE config-2 utterances of
-                              tests/test_gpu_forward.py::test_config2_slice_matches_oracle (pins the oracle run on
-                              the GPU box to the one made here).
+  config2_oracle_digest.json  mean/std of the well-conditioned oracle stages (duration, F0, N, decoder output) for the
+                              two BASELINE config-2 utterances of tests/test_gpu_forward.py::
+                              test_config2_slice_matches_oracle: pins the oracle run on the GPU box's CPU to the one
+                              made here.  (The waveform itself is NOT reproducible across CPUs: it is chaotic in the
+                              float32 round-off of F0, see DESIGN.md "conditioning".)
 """
 import json
 import os
@@ -61,8 +63,11 @@ def main():
     noise = rng2.standard_normal((2, 600 * Fmax, 9)).astype(np.float32)
     out = {"utt": []}
     for b in range(2):
-        a, _ = orc.forward(utts[b], ref[b : b + 1], 1.0, forced_dur=np.full(130, 5, np.int32), sine_noise=noise[b : b + 1])
-        out["utt"].append({"max_abs": float(np.abs(a).max()), "std": float(a.astype(np.float64).std()), "samples": int(a.shape[0])})
+        a, pd, it = orc.forward(utts[b], ref[b : b + 1], 1.0, forced_dur=np.full(130, 5, np.int32), sine_noise=noise[b : b + 1], return_inter=True)
+        st = lambda v: [float(np.mean(v, dtype=np.float64)), float(np.std(v, dtype=np.float64))]
+        out["utt"].append({"samples": int(a.shape[0]), "wav_std": float(a.astype(np.float64).std()), "F0_pred": st(it["F0_pred"]),
+                           "N_pred": st(it["N_pred"]), "dec_out": st(it["dec_out"]), "duration": st(it["duration"]),
+                           "pred_dur_sum": int(pd.sum())})
         print("config2 utt", b, out["utt"][-1])
     json.dump(out, open(os.path.join(HERE, "config2_oracle_digest.json"), "w"), indent=1)
 

@@ -110,3 +110,22 @@ def test_oracle_forward_tiny_deterministic():
     # rand_ini cannot change the output (see KokoroOracle.sine_gen docstring)
     a3, _ = o.forward(ids, ref_s, 1.0, rand_ini=rng.standard_normal((1, 9)).astype(np.float32))
     np.testing.assert_array_equal(a1, a3)
+
+
+def test_oracle_reproduces_committed_golden_case():
+    """tests/golden/tiny_case.npz: the well-conditioned stages (durations, F0, N) reproduce on any CPU; the waveform
+    reproduces when the vocoder is conditioned on the fixture's F0 / N curves (DESIGN.md "conditioning")."""
+    import os
+
+    case = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_case.npz"))
+    cfg = P.tiny_config()
+    o = O.KokoroOracle(P.synth_checkpoint(cfg, 0), cfg)
+    ids = case["ids"].tolist()
+    F = int(case["pred_dur"].sum())
+    noise = np.random.default_rng(int(case["noise_seed"])).standard_normal((1, 600 * F, 9)).astype(np.float32)
+    a, d, it = o.forward(ids, case["ref_s"], 1.0, sine_noise=noise, return_inter=True)
+    np.testing.assert_array_equal(d, case["pred_dur"])
+    np.testing.assert_allclose(it["F0_pred"], case["F0_pred"], rtol=0, atol=2e-4 * np.abs(case["F0_pred"]).max())
+    np.testing.assert_allclose(it["N_pred"], case["N_pred"], rtol=0, atol=2e-4 * np.abs(case["N_pred"]).max())
+    a2, _ = o.forward(ids, case["ref_s"], 1.0, sine_noise=noise, f0n_override=(case["F0_pred"], case["N_pred"]))
+    assert np.abs(a2 - case["audio"]).max() <= 1e-3 * max(1.0, np.abs(case["audio"]).max())
