@@ -110,6 +110,12 @@ int kk_op_conv1d(void* stream, int B, const void* x, int ldx, int Lin_rows, cons
                  const float* bias, int Cin, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift, float in_slope,
                  int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out, int ldo, int Lout_rows,
                  const int32_t* lout, int in_dtype, int out_dtype);
+/* the same ops on the bf16 MFMA kernel.  w_bf16 packed [Kw][CoutP][CinP] (CinP % 64 == 0, CoutP % 128 == 0, zero padded),
+ * x bf16 with ldx >= CinP, out bf16 or fp32 (out_dtype), bias [CoutP]. */
+int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, int Lin_rows, const int32_t* lin, const void* w_bf16, int CinP, int CoutP,
+                      const float* bias, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift, float in_slope,
+                      int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out, int ldo, int Lout_rows,
+                      const int32_t* lout, int out_dtype);
 /* InstanceNorm statistics + AdaIN1d + activation (+ pool)  --  istftnet.py:216-268,327-338,382,874-882 */
 int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta, int gbs,
                 int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out, int ldo, int Cpad,
@@ -138,6 +144,7 @@ int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channel
 int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
 int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
 void kk_debug_clear(kk_model* m);
+void kk_debug_force_generic(kk_model* m, int on); /* bf16 mode without the MFMA kernel (A/B tests) */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention

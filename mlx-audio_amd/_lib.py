@@ -41,6 +41,7 @@ SIGNATURES = {
     "kk_last_error": (C.c_char_p, []),
     "kk_abi_version": (_i, []),
     "kk_op_conv1d": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _f, _i, _vp, _i, _i, _vp, _i, _i]),
+    "kk_op_conv1d_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _f, _i, _vp, _i, _i, _vp, _i]),
     "kk_op_adain": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _i]),
     "kk_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _f, _vp, _i, _i]),
     "kk_op_lstm": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
@@ -51,6 +52,7 @@ SIGNATURES = {
     "kk_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_override": (_i, [_vp, C.c_char_p, _vp]),
     "kk_debug_clear": (None, [_vp]),
+    "kk_debug_force_generic": (None, [_vp, _i]),
     "kk_profile_begin": (_i, [_vp, _i]),
     "kk_profile_end": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

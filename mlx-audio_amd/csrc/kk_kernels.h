@@ -5,6 +5,31 @@
 // ---- convolution family (kk_conv.hip, kk_conv_mfma.hip)
 int kk_launch_conv_generic(const KKConvArgs& a, int B, int in_dtype, int out_dtype, hipStream_t st);
 
+// bf16 MFMA implicit-GEMM convolution (kk_conv_mfma.hip)
+struct KKMfmaArgs {
+  const bf16_t* x;  // [B][rows][ldx], ldx >= CinP, pad channels finite (zero)
+  long long xbs;
+  int ldx;
+  const bf16_t* w;  // packed [Kw][CoutP][CinP], zero padded
+  int CinP, CoutP;
+  const float* bias;  // [CoutP] or null
+  void* out;          // bf16 or fp32
+  long long obs;
+  int ldo;
+  const void* res;  // same dtype as out
+  long long rbs;
+  int ldr;
+  int Cout;  // channels actually written (multiple of 8)
+  int Kw, mode, stride, pad, dil, in_shift;
+  int Q, Lo_rows;
+  KKLen lin, lout;
+  float in_slope, scale;
+  int accumulate, act;
+  float act_slope;
+};
+bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
+int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
+
 // ---- normalisation family (kk_norm.hip)
 struct KKStatsArgs {
   const void* x;

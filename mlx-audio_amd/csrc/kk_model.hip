@@ -52,6 +52,11 @@ struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
   int Cin = 0, Cout = 0, Kw = 0, ldw = 0;
   const float* w = nullptr;
   const float* b = nullptr;
+  // bf16 MFMA pack [Kw][CoutP][CinP] (bf16 mode, eligible layers only); bias is then padded to CoutP
+  bool mfma = false;
+  size_t wb_off = 0;
+  int CinP = 0, CoutP = 0;
+  const bf16_t* wb = nullptr;
 };
 struct VecW {
   size_t off = 0;
@@ -131,6 +136,7 @@ struct kk_model {
   std::map<std::string, const float*> dbg_over;
 
   // optional per-kernel-class timing (kk_profile_*): HIP events around every launch of a class
+  bool force_generic = false;  // tests: run the bf16 mode without the MFMA kernel
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs
   struct ProfRec { int cls; double flops; double bytes; };
@@ -186,6 +192,14 @@ static float f16_to_f32(uint16_t h) {
   float r;
   memcpy(&r, &u, 4);
   return r;
+}
+
+static uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
 }
 
 static std::string normalise_name(const std::string& in) {
@@ -303,6 +317,20 @@ struct Packer {
     }
     return true;
   }
+  // bf16 MFMA pack of wsrc[o][k][i] -> [k][CoutP][CinP] (two bf16 per float slot of the staging vector)
+  void pack_mfma(ConvW& c, const std::vector<float>& wsrc, int O, int K, int I) {
+    if (m->adt != KK_BF16 || O % 8 != 0 || O < 64 || I < 32) return;
+    c.mfma = true;
+    c.CinP = kk_cdiv(I, 64) * 64;
+    c.CoutP = kk_cdiv(O, 128) * 128;
+    const size_t nel = (size_t)K * c.CoutP * c.CinP;
+    c.wb_off = alloc((nel + 1) / 2);
+    uint16_t* dst = (uint16_t*)&m->pack[c.wb_off];
+    memset(dst, 0, nel * 2);
+    for (int o = 0; o < O; ++o)
+      for (int k = 0; k < K; ++k)
+        for (int i = 0; i < I; ++i) dst[((size_t)k * c.CoutP + o) * c.CinP + i] = f32_to_bf16_rne(wsrc[((size_t)o * K + k) * I + i]);
+  }
   // pack a conv weight given as wsrc[o][k][i] into [k][i][ldw]
   ConvW pack_oki(const std::vector<float>& wsrc, int O, int K, int I, const std::vector<float>* bias) {
     ConvW c;
@@ -312,9 +340,11 @@ struct Packer {
     for (int o = 0; o < O; ++o)
       for (int k = 0; k < K; ++k)
         for (int i = 0; i < I; ++i) dst[((size_t)k * I + i) * c.ldw + o] = wsrc[((size_t)o * K + k) * I + i];
+    pack_mfma(c, wsrc, O, K, I);
     if (bias) {
       c.has_bias = true;
-      c.b_off = alloc(O);
+      const int nb = c.mfma ? c.CoutP : O;
+      c.b_off = alloc(nb);
       memcpy(&m->pack[c.b_off], bias->data(), (size_t)O * 4);
     }
     return c;
@@ -332,17 +362,12 @@ struct Packer {
     std::vector<float> w, b;
     if (!folded(prefix, Cin, K, Cout, w)) return ConvW();
     if (!vec(prefix + ".bias", (size_t)Cout, b)) return ConvW();
-    ConvW c;
-    c.Cin = Cin; c.Cout = Cout; c.Kw = K; c.ldw = kk_cdiv(Cout, 64) * 64;
-    c.w_off = alloc((size_t)K * Cin * c.ldw);
-    float* dst = &m->pack[c.w_off];
+    // re-index [i][k][o] as [o][k][i]: the packed forms ([k][i][o] fp32, [k][o][i] bf16) are the same for both kinds of conv
+    std::vector<float> woki((size_t)Cout * K * Cin);
     for (int i = 0; i < Cin; ++i)
       for (int k = 0; k < K; ++k)
-        for (int o = 0; o < Cout; ++o) dst[((size_t)k * Cin + i) * c.ldw + o] = w[((size_t)i * K + k) * Cout + o];
-    c.has_bias = true;
-    c.b_off = alloc(Cout);
-    memcpy(&m->pack[c.b_off], b.data(), (size_t)Cout * 4);
-    return c;
+        for (int o = 0; o < Cout; ++o) woki[((size_t)o * K + k) * Cin + i] = w[((size_t)i * K + k) * Cout + o];
+    return pack_oki(woki, Cout, K, Cin, &b);
   }
   // nn.Conv1d: weight [O][K][I] (+ PyTorch [O][I][K]), bias [O]
   ConvW conv_plain(const std::string& prefix, int O, int K, int I) {
@@ -452,6 +477,7 @@ ResBlock1 build_resblock1(Packer& P, StyleBuilder& S, const std::string& p, int 
 void resolve(kk_model* m, ConvW& c) {
   c.w = m->dev + c.w_off;
   c.b = c.has_bias ? m->dev + c.b_off : nullptr;
+  c.wb = c.mfma ? (const bf16_t*)(m->dev + c.wb_off) : nullptr;
 }
 void resolve(kk_model* m, VecW& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_model* m, LstmW& l) { resolve(m, l.in); resolve(m, l.whT); }
@@ -703,6 +729,23 @@ struct Ctx {
     const double flops = 2.0 * B * rows_out * w.Cout * w.Cin * taps;
     const double bytes = B * (rows_out * w.Cout * esz(out.dtype) * (o.res ? 2.0 : 1.0) + (double)Q * (o.mode == KK_CONVT ? 1 : o.stride) * w.Cin * esz(x.dtype)) +
                          (double)w.Kw * w.Cin * w.Cout * 4.0;
+    const bool al16 = !(((uintptr_t)x.p | (uintptr_t)out.p | (uintptr_t)(o.res ? o.res->p : nullptr)) & 15);
+    if (w.mfma && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
+        kk_mfma_eligible(w.Cin, w.Cout, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
+        (!o.res || o.res->ld % 8 == 0) && al16 && !m->force_generic) {
+      KKMfmaArgs g;
+      memset(&g, 0, sizeof g);
+      g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
+      g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
+      if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
+      g.Cout = w.Cout; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
+      g.Q = Q; g.Lo_rows = out.rows; g.lin = lin; g.lout = lout; g.in_slope = o.in_slope; g.scale = o.scale; g.accumulate = o.accumulate;
+      g.act = o.act; g.act_slope = o.act_slope;
+      prof_start();
+      const int rc = kk_launch_conv_mfma(g, B, out.dtype, st);
+      prof_stop(1, flops, bytes);
+      return rc;
+    }
     prof_start();
     const int rc = kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
     prof_stop(0, flops, bytes);
@@ -780,7 +823,7 @@ int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in
   KKLen lout = lin;
   if (r.up) { lout.mul = lin.mul * 2; lout.add = lin.add * 2; }
   KK_TRY(c.stats(x, r.Cin, Lmax_in, lin));
-  KK_TRY(c.adain(x, r.Cin, lin, bufA, rup(r.Cin, 32) <= bufA.ld ? rup(r.Cin, 32) : r.Cin, Lmax_out, style + r.n1.off, gbs, KK_ACT_LRELU,
+  KK_TRY(c.adain(x, r.Cin, lin, bufA, rup(r.Cin, 64) <= bufA.ld ? rup(r.Cin, 64) : r.Cin, Lmax_out, style + r.n1.off, gbs, KK_ACT_LRELU,
                  0.2f, nullptr, r.up ? 1 : 0, r.pool_w.p, r.pool_b.p));
   ConvOpt o1;
   o1.pad = 1;
@@ -938,8 +981,10 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   }
   const KKLen lF{lenF, 1, 0}, l2{lenF, 2, 0}, l20{lenF, 2 * u0, 0}, lTf{lens4 + 2 * B, 1, 0}, lTfm1{lenF, 2 * u0 * u1, 0};
   Buf en = c.act(Fmax, H + S);
-  const int ld514 = rup(H + 2, 32), ldcat = rup(DH + 2 + 64, 32);
+  const int ld514 = rup(H + 2, 64), ldcat = rup(DH + 2 + 64, 64);
   Buf cat514 = c.act(Fmax, ld514);
+  if (!c.dry && hipMemsetAsync(cat514.p, 0, (size_t)B * cat514.bs * (c.adt == KK_F32 ? 4 : 2), c.st) != hipSuccess)
+    return kk_fail("kk_forward_audio: memset failed");  // pad channels feed zero weights: they must be finite
   if (!c.dry) {
     KK_TRY(kk_launch_gather_rows(ts.d.p, ts.d.bs, ts.d.ld, frame_idx, Fmax, lenF, en.p, en.bs, en.ld, 0, H + S, B, en.dtype, c.st));
     KK_TRY(kk_launch_gather_rows(ts.t_en.p, ts.t_en.bs, ts.t_en.ld, frame_idx, Fmax, lenF, cat514.p, cat514.bs, cat514.ld, 0, H, B,
@@ -986,6 +1031,11 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   KK_TRY(c.dbg("N_pred", f0n[1], 1));
   // ---- Decoder (istftnet.py:947-963)
   Buf catA = c.act(Fmax, ldcat), catB = c.act(Fmax, ldcat);
+  if (!c.dry) {  // pad channels of the concat buffers feed zero weights: they must be finite
+    const size_t es = c.adt == KK_F32 ? 4 : 2;
+    if (hipMemsetAsync(catA.p, 0, (size_t)B * catA.bs * es, c.st) != hipSuccess || hipMemsetAsync(catB.p, 0, (size_t)B * catB.bs * es, c.st) != hipSuccess)
+      return kk_fail("kk_forward_audio: memset failed");
+  }
   {
     ConvOpt o;
     o.stride = 2;
@@ -1180,6 +1230,23 @@ extern "C" int kk_op_conv1d(void* stream, int B, const void* x, int ldx, int Lin
   return kk_launch_conv_generic(a, B, in_dtype, out_dtype, (hipStream_t)stream);
 }
 
+extern "C" int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, int Lin_rows, const int32_t* lin, const void* w_bf16, int CinP,
+                                 int CoutP, const float* bias, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift,
+                                 float in_slope, int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out,
+                                 int ldo, int Lout_rows, const int32_t* lout, int out_dtype) {
+  KKMfmaArgs g;
+  memset(&g, 0, sizeof g);
+  g.x = (const bf16_t*)x; g.xbs = (long long)Lin_rows * ldx; g.ldx = ldx; g.w = (const bf16_t*)w_bf16; g.CinP = CinP; g.CoutP = CoutP; g.bias = bias;
+  g.out = out; g.obs = (long long)Lout_rows * ldo; g.ldo = ldo; g.res = res; g.rbs = (long long)Lout_rows * ldr; g.ldr = ldr;
+  g.Cout = Cout; g.Kw = Kw; g.mode = transposed ? KK_CONVT : KK_CONV; g.stride = stride; g.pad = pad; g.dil = dil; g.in_shift = in_shift;
+  g.Q = transposed ? kk_cdiv(Lout_rows, stride) : Lout_rows; g.Lo_rows = Lout_rows;
+  g.lin = KKLen{lin, lin ? 1 : 0, lin ? 0 : Lin_rows};
+  g.lout = KKLen{lout, lout ? 1 : 0, lout ? 0 : Lout_rows};
+  g.in_slope = in_slope; g.scale = scale; g.accumulate = accumulate; g.act = act; g.act_slope = act_slope;
+  if (!kk_mfma_eligible(CinP, Cout, Kw, g.mode, stride, dil)) return kk_fail("kk_op_conv1d_bf16: shape not eligible for the MFMA kernel");
+  return kk_launch_conv_mfma(g, B, out_dtype, (hipStream_t)stream);
+}
+
 extern "C" int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta,
                            int gbs, int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out,
                            int ldo, int Cpad, int Lout_rows, float* scratch, size_t scratch_floats, int dtype, int fast) {
@@ -1268,6 +1335,9 @@ extern "C" int kk_debug_override(kk_model* m, const char* name, const float* src
   if (!m || !name || !src) return kk_fail("kk_debug_override: null argument");
   m->dbg_over[name] = src;
   return 0;
+}
+extern "C" void kk_debug_force_generic(kk_model* m, int on) {
+  if (m) m->force_generic = on != 0;
 }
 extern "C" void kk_debug_clear(kk_model* m) {
   if (!m) return;
