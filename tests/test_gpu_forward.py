@@ -292,3 +292,46 @@ def test_generator_in_isolation_with_oracle_inputs():
     e = err_stats(wav.cpu().numpy()[0], r["o_audio"][0])
     report("tiny/generator_isolated/wav", **e)
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+
+
+def test_bf16_mode_tracks_fp32_oracle():
+    """bf16 mode (bf16 activations + bf16 MFMA convolutions, fp32 accumulation) against the fp32 oracle.  bf16 keeps 8
+    significant bits, so the bar here is statistical: well-conditioned stages within a few % RMS of the oracle, and the
+    MFMA kernel path within the same distance of the oracle as the plain-FMA bf16 path (kernel choice adds no error)."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.kokoro_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(60)
+    utts = [rng.integers(1, 178, 30).tolist() for _ in range(2)]
+    ref_s = _style_rows(rng, 2)
+    orc = O.KokoroOracle(w, cfg)
+    eng = _engine(cfg, w, "bfloat16")
+    dev = eng.device
+    ids, lens, Tmax = eng.pack_ids(utts)
+    durs = np.full((2, Tmax), 4, np.int32)
+    Fmax = int(durs.sum(1).max())
+    inters = []
+    for b in range(2):
+        _, _, it = orc.forward(utts[b], ref_s[b : b + 1], 1.0, forced_dur=durs[b], sine_noise=None, return_inter=True)
+        inters.append(it)
+    res = {}
+    for mode in ("mfma", "generic"):
+        eng.lib.kk_debug_force_generic(eng._h, 1 if mode == "generic" else 0)
+        eng.forward(ids, lens, torch.tensor(ref_s, device=dev), torch.ones(2, device=dev), Fmax, forced_dur=torch.tensor(durs, device=dev),
+                    noise_mode=_lib.NOISE_ZERO)
+        torch.cuda.synchronize()
+        for name, lay in (("bert_dur", None), ("d", None), ("t_en", "ncl"), ("F0_pred", "vec"), ("N_pred", "vec"), ("dec_out", "ncl")):
+            got = eng.debug_fetch(name).cpu().numpy()
+            for b in range(2):
+                ref = inters[b][name]
+                ref = ncl_to_nlc(ref)[0] if lay == "ncl" else (np.asarray(ref).reshape(-1, 1) if lay == "vec" else np.asarray(ref)[0])
+                e = err_stats(got[b, : ref.shape[0], : ref.shape[1]], ref)
+                report(f"bf16/{mode}/{name}/b{b}", **e)
+                res[(mode, name, b)] = e["rms_rel"]
+    eng.lib.kk_debug_force_generic(eng._h, 0)
+    for (mode, name, b), v in res.items():
+        assert v < 0.05, (mode, name, b, v)
+    for name in ("bert_dur", "d", "t_en", "dec_out"):
+        for b in range(2):
+            assert res[("mfma", name, b)] < 2.0 * res[("generic", name, b)] + 2e-3, (name, b, res[("mfma", name, b)], res[("generic", name, b)])

@@ -372,3 +372,123 @@ def test_istft_head(lib):
             report(f"istft_head/b{b}", **e)
             assert e["rel_max"] < 2e-5
         assert np.all(got[b, 5 * (n - 1) :] == 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 MFMA convolution kernel
+# ------------------------------------------------------------------------------------------------
+def pack_w_bf16(w_oki):
+    O_, K, I = w_oki.shape
+    CinP, CoutP = (I + 63) // 64 * 64, (O_ + 127) // 128 * 128
+    p = np.zeros((K, CoutP, CinP), np.float32)
+    p[:, :O_, :I] = np.transpose(w_oki, (1, 0, 2))
+    return torch.tensor(p).to(torch.bfloat16), CinP, CoutP
+
+
+def run_conv_bf16(lib, x_nlc, w_oki, bias, *, transposed=False, stride=1, pad=0, dil=1, in_shift=0, in_slope=1.0, act=0, act_slope=0.0,
+                  res=None, scale=1.0, accumulate=False, out_init=None, Lout=None, lin=None, lout=None, out_f32=False):
+    from mlx_audio_amd import _lib
+
+    B, Lin, Cin = x_nlc.shape
+    O_ = w_oki.shape[0]
+    wp, CinP, CoutP = pack_w_bf16(w_oki)
+    xpad = np.zeros((B, Lin, CinP), np.float32)
+    xpad[:, :, :Cin] = x_nlc
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    xd, wd = dev(xpad, torch.bfloat16), wp.cuda().contiguous()
+    bp = np.zeros(CoutP, np.float32)
+    if bias is not None:
+        bp[:O_] = bias
+    bd = dev(bp)
+    out = dev(out_init, odt) if out_init is not None else torch.full((B, Lout, O_), 7.0, device="cuda", dtype=odt)
+    rd = dev(res, odt) if res is not None else None
+    lind = dev(np.asarray(lin, np.int32), torch.int32) if lin is not None else None
+    loutd = dev(np.asarray(lout, np.int32), torch.int32) if lout is not None else None
+    rc = lib.kk_op_conv1d_bf16(stream(), B, P(xd), CinP, Lin, P(lind), P(wd), CinP, CoutP, P(bd), O_, w_oki.shape[1], int(transposed), stride,
+                               pad, dil, in_shift, in_slope, act, act_slope, P(rd), O_, scale, int(accumulate), P(out), O_, Lout, P(loutd),
+                               _lib.KK_F32 if out_f32 else _lib.KK_BF16)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def _bf(a):
+    return torch.tensor(a).to(torch.bfloat16).float().numpy()
+
+
+MFMA_CASES = [
+    # name, Cin, Cout, K, pad, dil, L
+    ("gen_k3", 128, 128, 3, 1, 1, 1000),
+    ("gen_k7_d3", 128, 128, 7, 9, 3, 777),
+    ("gen_k11_d5", 256, 256, 11, 25, 5, 300),
+    ("dec_k3_cin1090", 1090, 256, 3, 1, 1, 131),
+    ("linear_768_2304", 768, 2304, 1, 0, 1, 130),
+    ("cout64_cin514", 514, 64, 1, 0, 1, 70),
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES, ids=[c[0] for c in MFMA_CASES])
+def test_conv_mfma_bf16(lib, case):
+    name, Cin, Cout, K, p, d, L = case
+    rng = np.random.default_rng(hash(name) % 2**31)
+    B = 2
+    x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+    w = _bf((rng.standard_normal((Cout, K, Cin)) / math.sqrt(K * Cin)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv1d(torch.tensor(x).transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(b), 1, p, d).transpose(1, 2).numpy()
+    got32 = run_conv_bf16(lib, x, w, b, pad=p, dil=d, Lout=L, out_f32=True)
+    e = err_stats(got32, ref)
+    report(f"conv_mfma/{name}/f32out", **e)
+    assert e["rel_max"] < 2e-5  # same bf16 operands, fp32 accumulation: summation order only
+    got = run_conv_bf16(lib, x, w, b, pad=p, dil=d, Lout=L)
+    e = err_stats(got, ref)
+    report(f"conv_mfma/{name}/bf16out", **e)
+    assert e["rel_max"] < 5e-3  # one bf16 rounding of the result (2^-9 relative)
+
+
+def test_conv_mfma_epilogue_and_ragged(lib):
+    rng = np.random.default_rng(33)
+    B, L, C, K, d = 3, 300, 128, 7, 3
+    lens = [300, 129, 5]
+    x = _bf(rng.standard_normal((B, L, C)).astype(np.float32))
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    w = _bf((rng.standard_normal((C, K, C)) / math.sqrt(K * C)).astype(np.float32))
+    bias = rng.standard_normal(C).astype(np.float32)
+    res = _bf(rng.standard_normal((B, L, C)).astype(np.float32))
+    init = _bf(rng.standard_normal((B, L, C)).astype(np.float32))
+    got = run_conv_bf16(lib, x, w, bias, pad=9, dil=d, in_slope=0.1, res=res, scale=1 / 3, accumulate=True, out_init=init, Lout=L, lin=lens,
+                        lout=lens, out_f32=False)
+    for b, n in enumerate(lens):
+        xin = np.where(x[b, :n] > 0, x[b, :n], _bf(x[b, :n] * 0.1))
+        base = F.conv1d(torch.tensor(xin)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 9, d).transpose(1, 2)[0]
+        ref = ((base + torch.tensor(res[b, :n])) * (1 / 3) + torch.tensor(init[b, :n])).numpy()
+        e = err_stats(got[b, :n], ref)
+        report(f"conv_mfma/epilogue_ragged/b{b}", **e)
+        assert e["rel_max"] < 6e-3
+        assert np.all(got[b, n:] == 0)
+
+
+@pytest.mark.parametrize("cfg", [(20, 10, 5, 512, 256, 130), (12, 6, 3, 256, 128, 300)], ids=["ups0", "ups1"])
+def test_conv_transpose_mfma(lib, cfg):
+    K, s, p, Cin, Cout, L = cfg
+    rng = np.random.default_rng(K + 100)
+    B = 2
+    x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+    w_iko = _bf((rng.standard_normal((Cin, K, Cout)) / math.sqrt(K * Cin / s)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv_transpose1d(torch.tensor(x).transpose(1, 2), torch.tensor(w_iko).permute(0, 2, 1), torch.tensor(b), s, p).transpose(1, 2).numpy()
+    got = run_conv_bf16(lib, x, np.transpose(w_iko, (2, 1, 0)), b, transposed=True, stride=s, pad=p, Lout=ref.shape[1], out_f32=True)
+    e = err_stats(got, ref)
+    report(f"convT_mfma/k{K}s{s}", **e)
+    assert e["rel_max"] < 2e-5
+
+
+def test_conv1x1_mfma_upsampled_input(lib):
+    rng = np.random.default_rng(19)
+    B, L, Cin, Cout = 2, 141, 1090, 512
+    x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+    w = _bf((rng.standard_normal((Cout, 1, Cin)) / math.sqrt(Cin)).astype(np.float32))
+    ref = np.einsum("blc,oc->blo", np.repeat(x, 2, axis=1), w[:, 0, :])
+    got = run_conv_bf16(lib, x, w, None, in_shift=1, Lout=2 * L, out_f32=True)
+    assert err_stats(got, ref)["rel_max"] < 2e-5
