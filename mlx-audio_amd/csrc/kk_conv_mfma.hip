@@ -15,6 +15,8 @@
 //   * epilogue through LDS (fp32 tile) so bias / activation / residual / scale / accumulate / length mask are applied
 //     on coalesced 16-byte rows and the result is rounded to bf16 exactly once.
 #include "kk_common.h"
+#include <stdlib.h>
+
 #include "kk_kernels.h"
 
 namespace {
@@ -39,6 +41,10 @@ __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f +
 union U16 {
   uint4 u;
   bf16_t h[8];
+};
+union U32x8 {
+  uint4 u[2];
+  float f[8];
 };
 
 template <typename TO>
@@ -88,20 +94,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
     // ---- loaders (global -> registers) --------------------------------------------------------------
     uint4 xreg[6];  // up to 192 rows x 8 chunks of 16 B = 1536 chunks / 256 threads
     uint4 wreg[4];  // 128 rows x 8 chunks = 1024 chunks / 256 threads
+    // Unconditional loads from clamped addresses; validity is applied when the registers are written to LDS.  A load under
+    // a data-dependent branch (or a select the optimiser turns into one) makes hipcc wait vmcnt(0) right behind it, which
+    // serialises the six loads (one HBM round trip each); the empty asm with a memory clobber keeps the loads from being
+    // sunk towards their use.
+    const int lin_hi = Lin > 0 ? Lin - 1 : 0;
+    unsigned xok = 0;
     auto load_x = [&](int chunk) {
+      xok = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int id = i * 256 + tid;
         const int r = id >> 3, c8 = (id & 7) * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < xrows) {
-          int row = q0 + min_off + r;
-          const bool ok0 = row >= 0;
-          if (a.in_shift) row >>= a.in_shift;
-          if (ok0 && row < Lin) v = *(const uint4*)(xb + (long long)row * a.ldx + chunk * CK + c8);
-        }
-        xreg[i] = v;
+        int row = q0 + min_off + r;
+        const bool ok0 = row >= 0 && r < xrows;
+        if (a.in_shift) row >>= a.in_shift;
+        if (ok0 && row < Lin) xok |= 1u << i;
+        const int rc = row < 0 ? 0 : (row > lin_hi ? lin_hi : row);
+        xreg[i] = *(const uint4*)(xb + (long long)rc * a.ldx + chunk * CK + c8);
       }
+      asm volatile("" ::: "memory");
     };
     auto store_x = [&]() {
 #pragma unroll
@@ -110,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
         const int r = id >> 3, c8 = (id & 7) * 8;
         if (r < xrows) {
           U16 t;
-          t.u = xreg[i];
+          const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
+          t.u = make_uint4(xreg[i].x & msk, xreg[i].y & msk, xreg[i].z & msk, xreg[i].w & msk);
           if (a.in_slope != 1.0f) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
       }
     };
     auto load_w = [&](int it) {
+      if ((a.dbg & 1) && it > 1) return;  // timing experiment: no W traffic after the prologue
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
       const bf16_t* wt = a.w + ((long long)(widx0 + tap * wstep) * a.CoutP + n0) * a.CinP + chunk * CK;
 #pragma unroll
@@ -131,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
         const int n = id >> 3, c8 = (id & 7) * 8;
         wreg[i] = *(const uint4*)(wt + (long long)n * a.CinP + c8);
       }
+      asm volatile("" ::: "memory");
     };
     auto store_w = [&](bf16_t* Ws) {
 #pragma unroll
@@ -156,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
     for (int it = 0; it < nit; ++it) {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
       const bf16_t* Ws = (it & 1) ? Ws1 : Ws0;
-      // prefetch the next channel slab of X while the last tap of this slab computes
+      // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land
       const bool last_tap = tap == ntaps - 1;
-      if (last_tap && chunk + 1 < nchunk) load_x(chunk + 1);
+      if (tap == 0 && chunk + 1 < nchunk && !(a.dbg & 2)) load_x(chunk + 1);
 
       const int shift = (off0 + tap * dstep) - min_off;  // row shift of this tap inside the X slab
       const bf16_t* xa = Xs + (arow + shift) * XLD + kofs;
@@ -208,45 +223,95 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
   }
   TO* ob = (TO*)a.out + (long long)b * a.obs;
   const TO* rb = a.res ? (const TO*)a.res + (long long)b * a.rbs : nullptr;
+  const int n = n0 + (tid & 15) * 8;  // this thread's 8 output channels (same for all its rows)
+  const int lo_hi = a.Lo_rows - 1;
+  constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int id = i * 256 + tid;
-    const int row = id >> 4, c8 = (id & 15) * 8;
-    const int q = q0 + row;
-    if (q >= a.Q) continue;
-    const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
-    if (op >= a.Lo_rows) continue;
-    const int n = n0 + c8;
-    if (n >= a.Cout) continue;
-    float v[8];
-    const bool live = tile_live && op < Lout;
-    if (live) {
-      const float4 c0 = *(const float4*)(Cs + row * CLD + c8);
-      const float4 c1 = *(const float4*)(Cs + row * CLD + c8 + 4);
-      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+  for (int half = 0; half < 2; ++half) {
+    int opv[4];
+    bool wr_ok[4], live[4];
+    uint4 rres[4][VEC], rold[4][VEC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ((half * 4 + i) * 256 + tid) >> 4;
+      const int q = q0 + row;
+      const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
+      opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
+      wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
+      live[i] = tile_live && op < Lout;
+    }
+    const int nc = n < a.Cout ? n : 0;  // clamped channel for the unconditional loads
+    if (rb) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
+    }
+    if (a.accumulate) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) rold[i][v] = *((const uint4*)(ob + (long long)opv[i] * a.ldo + nc) + v);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ((half * 4 + i) * 256 + tid) >> 4;
+      float v[8];
+      if (tile_live) {
+        const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
+        const float4 c1 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8 + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+      }
       if (rb) {
+        if (sizeof(TO) == 2) {
+          U16 t;
+          t.u = rres[i][0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += kk_ld(rb + (long long)op * a.ldr + n + k);
+          for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+        } else {
+          U32x8 t;
+          t.u[0] = rres[i][0];
+          t.u[1] = rres[i][VEC - 1];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] *= a.scale;
       if (a.accumulate) {
+        if (sizeof(TO) == 2) {
+          U16 t;
+          t.u = rold[i][0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += kk_ld(ob + (long long)op * a.ldo + n + k);
+          for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+        } else {
+          U32x8 t;
+          t.u[0] = rold[i][0];
+          t.u[1] = rold[i][VEC - 1];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+        }
       }
-    } else {
+      if (!live[i]) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = 0.f;
-    }
-    TO* dst = ob + (long long)op * a.ldo + n;
-    if (sizeof(TO) == 2) {
-      U16 t;
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+      }
+      if (wr_ok[i]) {
+        TO* dst = ob + (long long)opv[i] * a.ldo + n;
+        if (sizeof(TO) == 2) {
+          U16 t;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
-      *(uint4*)dst = t.u;
-    } else {
-      *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-      *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
+          *(uint4*)dst = t.u;
+        } else {
+          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
     }
   }
 }
@@ -276,10 +341,14 @@ int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t s
   }
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
   dim3 grid(kk_cdiv(a.Q, BM), a.CoutP / BN, B * nphase);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("KK_MFMA_DBG"); dbg = e ? atoi(e) : 0; }
+  KKMfmaArgs a2 = a;
+  a2.dbg = dbg;
   if (out_dtype == KK_BF16)
-    hipLaunchKernelGGL(conv_mfma_kernel<bf16_t>, grid, dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv_mfma_kernel<bf16_t>, grid, dim3(256), LDS_BYTES, st, a2);
   else
-    hipLaunchKernelGGL(conv_mfma_kernel<float>, grid, dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv_mfma_kernel<float>, grid, dim3(256), LDS_BYTES, st, a2);
   KK_CHECK_LAUNCH();
   return 0;
 }

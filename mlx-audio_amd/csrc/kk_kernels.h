@@ -26,6 +26,7 @@ struct KKMfmaArgs {
   float in_slope, scale;
   int accumulate, act;
   float act_slope;
+  int dbg;  // timing experiments only (KK_MFMA_DBG): bit0 skip W reloads, bit1 skip X reloads
 };
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);

@@ -1,0 +1,279 @@
+"""Host-side mirror of mlx_audio/tts/models/kokoro/pipeline.py + voice.py: voices, chunking, timestamps.
+
+G2P (misaki / espeak) is a third-party dependency of the reference and is not part of the hot path; when it is
+not importable the pipeline still serves phoneme strings (`generate_from_tokens`, pipeline.py:238-290) and accepts
+any callable `g2p(text) -> (phonemes, tokens)`.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import re
+from dataclasses import dataclass
+from numbers import Number
+from typing import Any, Callable, Generator, List, Optional, Tuple, Union
+
+import numpy as np
+
+ALIASES = {"en-us": "a", "en-gb": "b", "es": "e", "fr-fr": "f", "hi": "h", "it": "i", "pt-br": "p", "ja": "j", "zh": "z"}
+LANG_CODES = dict(a="American English", b="British English", e="es", f="fr-fr", h="hi", i="it", p="pt-br", j="Japanese",
+                  z="Mandarin Chinese")
+
+
+def load_voice_tensor(path: str) -> np.ndarray:
+    """A voice pack as a numpy array [510, 1, 256] (voice.py:9-81).  Formats: PyTorch `.pt` (read with
+    `torch.load(weights_only=True)`, which executes nothing from the file), `.npy`, `.npz` (first array),
+    `.safetensors` (first tensor) and the `.json` nested lists the reference's Swift package ships."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".pt":
+        import torch
+
+        return torch.load(path, map_location="cpu", weights_only=True).float().numpy()
+    if ext == ".npy":
+        return np.load(path, allow_pickle=False)
+    if ext == ".npz":
+        z = np.load(path, allow_pickle=False)
+        return z[z.files[0]]
+    if ext == ".safetensors":
+        from safetensors.numpy import load_file
+
+        d = load_file(path)
+        return d[sorted(d)[0]]
+    if ext == ".json":
+        with open(path) as f:
+            return np.asarray(json.load(f), dtype=np.float32)
+    raise ValueError(f"unsupported voice file: {path}")
+
+
+class KokoroPipeline:
+    """pipeline.py:45-460.  model=False gives a "quiet" pipeline that only phonemises / chunks."""
+
+    def __init__(self, lang_code: str, model, repo_id: str, trf: bool = False, g2p: Optional[Callable] = None):
+        lang_code = ALIASES.get(lang_code.lower(), lang_code.lower())
+        assert lang_code in LANG_CODES, (lang_code, LANG_CODES)
+        self.lang_code = lang_code
+        self.repo_id = repo_id
+        if repo_id is None:
+            raise ValueError("repo_id is required to load voices")
+        self.model = model
+        self.voices = {}
+        self.g2p = g2p
+        if g2p is None:
+            try:  # optional third-party G2P, exactly what the reference uses (pipeline.py:10,91-126)
+                from misaki import en, espeak  # type: ignore
+
+                if lang_code in "ab":
+                    try:
+                        fallback = espeak.EspeakFallback(british=lang_code == "b")
+                    except Exception as e:  # noqa: BLE001
+                        logging.warning("EspeakFallback not Enabled: OOD words will be skipped (%s)", e)
+                        fallback = None
+                    self.g2p = en.G2P(trf=trf, british=lang_code == "b", fallback=fallback, unk="")
+                else:
+                    self.g2p = espeak.EspeakG2P(language=LANG_CODES[lang_code])
+            except ImportError:
+                self.g2p = None  # phoneme-string entry points still work
+
+    # ---- voices (pipeline.py:129-161) ------------------------------------------------------------------
+    def load_single_voice(self, voice: str):
+        if voice in self.voices:
+            return self.voices[voice]
+        if os.path.exists(voice):
+            f = voice
+        else:
+            from huggingface_hub import hf_hub_download  # network; raises offline, like the reference
+
+            f = hf_hub_download(repo_id=self.repo_id, filename=f"voices/{voice}.pt")
+            if not voice.startswith(self.lang_code):
+                logging.warning("Language mismatch, loading %s voice into %s pipeline.", voice, LANG_CODES.get(self.lang_code))
+        pack = np.asarray(load_voice_tensor(f), dtype=np.float32)
+        self.voices[voice] = pack
+        return pack
+
+    def load_voice(self, voice: str, delimiter: str = ","):
+        """One voice or the mean of several ('af_bella,af_jessica')."""
+        if voice in self.voices:
+            return self.voices[voice]
+        packs = [self.load_single_voice(v) for v in voice.split(delimiter)]
+        if len(packs) == 1:
+            return packs[0]
+        self.voices[voice] = np.mean(np.stack(packs), axis=0)
+        return self.voices[voice]
+
+    # ---- chunking on duck-typed tokens (.phonemes, .whitespace, .text) (pipeline.py:163-226) -------------------
+    @classmethod
+    def tokens_to_ps(cls, tokens) -> str:
+        return "".join(t.phonemes + (" " if t.whitespace else "") for t in tokens).strip()
+
+    @classmethod
+    def tokens_to_text(cls, tokens) -> str:
+        return "".join(t.text + t.whitespace for t in tokens).strip()
+
+    @classmethod
+    def waterfall_last(cls, tokens, next_count: int, waterfall=("!.?…", ":;", ",—"), bumps=(")", "”")) -> int:
+        for w in waterfall:
+            z = next((i for i, t in reversed(list(enumerate(tokens))) if t.phonemes in set(w)), None)
+            if z is None:
+                continue
+            z += 1
+            if z < len(tokens) and tokens[z].phonemes in bumps:
+                z += 1
+            if next_count - len(cls.tokens_to_ps(tokens[:z])) <= 510:
+                return z
+        return len(tokens)
+
+    def en_tokenize(self, tokens) -> Generator[Tuple[str, str, list], None, None]:
+        tks, pcount = [], 0
+        for t in tokens:
+            t.phonemes = "" if t.phonemes is None else t.phonemes.replace("ɾ", "T")
+            next_ps = t.phonemes + (" " if t.whitespace else "")
+            next_pcount = pcount + len(next_ps.rstrip())
+            if next_pcount > 510:
+                z = KokoroPipeline.waterfall_last(tks, next_pcount)
+                yield KokoroPipeline.tokens_to_text(tks[:z]), KokoroPipeline.tokens_to_ps(tks[:z]), tks[:z]
+                tks = tks[z:]
+                pcount = len(KokoroPipeline.tokens_to_ps(tks))
+                if not tks:
+                    next_ps = next_ps.lstrip()
+            tks.append(t)
+            pcount += len(next_ps)
+        if tks:
+            yield KokoroPipeline.tokens_to_text(tks), KokoroPipeline.tokens_to_ps(tks), tks
+
+    # ---- inference ---------------------------------------------------------------------------------------
+    @classmethod
+    def infer(cls, model, ps: str, pack, speed: Number = 1):
+        # style row = pack[len(ps) - 1]: indexed by the phoneme-STRING length (pipeline.py:236)
+        return model(ps, pack[len(ps) - 1], speed, return_output=True)
+
+    def generate_from_tokens(self, tokens: Union[str, list], voice: str, speed: Number = 1, model=None):
+        model = model or self.model
+        if model and voice is None:
+            raise ValueError('Specify a voice: pipeline.generate_from_tokens(..., voice="af_heart")')
+        pack = self.load_voice(voice) if model else None
+        if isinstance(tokens, str):
+            if len(tokens) > 510:
+                raise ValueError(f"Phoneme string too long: {len(tokens)} > 510")
+            output = KokoroPipeline.infer(model, tokens, pack, speed) if model else None
+            yield self.Result(graphemes="", phonemes=tokens, output=output)
+            return
+        for gs, ps, tks in self.en_tokenize(tokens):
+            if not ps:
+                continue
+            if len(ps) > 510:
+                logging.warning("Unexpected len(ps) == %d > 510; truncating", len(ps))
+                ps = ps[:510]
+            output = KokoroPipeline.infer(model, ps, pack, speed) if model else None
+            if output is not None and output.pred_dur is not None:
+                KokoroPipeline.join_timestamps(tks, output.pred_dur)
+            yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output)
+
+    @classmethod
+    def join_timestamps(cls, tokens, pred_dur) -> None:
+        """pipeline.py:292-328: half-frame bookkeeping, 80 half-frames per second."""
+        MAGIC_DIVISOR = 80
+        pd = [int(v) for v in (pred_dur.tolist() if hasattr(pred_dur, "tolist") else pred_dur)]
+        if not tokens or len(pd) < 3:
+            return
+        left = right = 2 * max(0, pd[0] - 3)
+        i = 1
+        for t in tokens:
+            if i >= len(pd) - 1:
+                break
+            if not t.phonemes:
+                if t.whitespace:
+                    i += 1
+                    left = right + pd[i]
+                    right = left + pd[i]
+                    i += 1
+                continue
+            j = i + len(t.phonemes)
+            if j >= len(pd):
+                break
+            t.start_ts = left / MAGIC_DIVISOR
+            token_dur = sum(pd[i:j])
+            space_dur = pd[j] if t.whitespace else 0
+            left = right + (2 * token_dur) + space_dur
+            t.end_ts = left / MAGIC_DIVISOR
+            right = left + space_dur
+            i = j + (1 if t.whitespace else 0)
+
+    @dataclass
+    class Result:
+        graphemes: str
+        phonemes: str
+        tokens: Optional[list] = None
+        output: Optional[Any] = None
+        text_index: Optional[int] = None
+
+        @property
+        def audio(self):
+            return None if self.output is None else self.output.audio
+
+        @property
+        def pred_dur(self):
+            return None if self.output is None else self.output.pred_dur
+
+        def __iter__(self):
+            yield self.graphemes
+            yield self.phonemes
+            yield self.audio
+
+        def __getitem__(self, index):
+            return [self.graphemes, self.phonemes, self.audio][index]
+
+        def __len__(self):
+            return 3
+
+    def __call__(self, text: Union[str, List[str]], voice: Optional[str] = None, speed: Number = 1,
+                 split_pattern: Optional[str] = r"\n+"):
+        if voice is None:
+            raise ValueError('Specify a voice: en_us_pipeline(text="Hello world!", voice="af_heart")')
+        if self.g2p is None:
+            raise ImportError("text input needs a G2P: `pip install misaki[en]` (what the reference uses) or pass g2p=...; "
+                              "phoneme strings work through generate_from_tokens()")
+        pack = self.load_voice(voice) if self.model else None
+        if isinstance(text, str):
+            text = re.split(split_pattern, text.strip()) if split_pattern else [text]
+        for gi, graphemes in enumerate(text):
+            if not graphemes.strip():
+                continue
+            if self.lang_code in "ab":
+                _, tokens = self.g2p(graphemes)
+                for gs, ps, tks in self.en_tokenize(tokens):
+                    if not ps:
+                        continue
+                    if len(ps) > 510:
+                        ps = ps[:510]
+                    output = KokoroPipeline.infer(self.model, ps, pack, speed) if self.model else None
+                    if output is not None and output.pred_dur is not None:
+                        KokoroPipeline.join_timestamps(tks, output.pred_dur)
+                    yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output, text_index=gi)
+            else:
+                for chunk in _sentence_chunks(graphemes, 400):  # pipeline.py:408-436
+                    ps, _ = self.g2p(chunk)
+                    if not ps:
+                        continue
+                    if len(ps) > 510:
+                        ps = ps[:510]
+                    output = KokoroPipeline.infer(self.model, ps, pack, speed) if self.model else None
+                    yield self.Result(graphemes=chunk, phonemes=ps, output=output, text_index=gi)
+
+
+def _sentence_chunks(graphemes: str, chunk_size: int) -> List[str]:
+    sentences = re.split(r"([.!?]+)", graphemes)
+    chunks, cur = [], ""
+    for i in range(0, len(sentences), 2):
+        s = sentences[i] + (sentences[i + 1] if i + 1 < len(sentences) else "")
+        if len(cur) + len(s) <= chunk_size:
+            cur += s
+        else:
+            if cur:
+                chunks.append(cur.strip())
+            cur = s
+    if cur:
+        chunks.append(cur.strip())
+    if not chunks:
+        chunks = [graphemes[i : i + chunk_size] for i in range(0, len(graphemes), chunk_size)]
+    return [c for c in chunks if c.strip()]

@@ -1,0 +1,85 @@
+"""Host-side mirror of mlx_audio/tts/utils.py:150-268 (`load_model`) for the Kokoro path.
+
+A local directory with `config.json` + `*.safetensors` is loaded as is; both checkpoint layouts (PyTorch-side
+names / [O, I, K] convs, or MLX-side / [O, K, I]) are accepted.  There is no network here, so repo ids are only
+resolved through the local Hugging Face cache (`snapshot_download(local_files_only=True)`)."""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+from pathlib import Path
+from typing import Union
+
+MODEL_REMAPPING = {"kokoro": "kokoro"}
+
+
+def get_model_path(path_or_hf_repo: str, revision=None) -> Path:
+    p = Path(path_or_hf_repo)
+    if p.exists():
+        return p
+    from huggingface_hub import snapshot_download
+
+    return Path(snapshot_download(path_or_hf_repo, revision=revision, local_files_only=True,
+                                  allow_patterns=["*.json", "*.safetensors", "*.txt"]))
+
+
+def load_config(model_path: Union[str, Path]) -> dict:
+    model_path = get_model_path(model_path) if isinstance(model_path, str) else model_path
+    try:
+        with open(model_path / "config.json", encoding="utf-8") as f:
+            return json.load(f)
+    except FileNotFoundError as exc:
+        raise FileNotFoundError(f"Config not found at {model_path}") from exc
+
+
+def get_model_and_args(model_type: str, model_name):
+    """utils.py:77-121: only the Kokoro path exists in this engine."""
+    model_type = MODEL_REMAPPING.get(model_type, model_type)
+    for part in model_name or []:
+        if part in MODEL_REMAPPING:
+            model_type = MODEL_REMAPPING[part]
+    if model_type != "kokoro":
+        msg = f"Model type {model_type} not supported."
+        logging.error(msg)
+        raise ValueError(msg)
+    from . import kokoro
+
+    return kokoro, model_type
+
+
+def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtype: str = None, **kwargs):
+    """Returns a ready `kokoro.Model` (weights folded, packed and resident in HBM).
+    Raises FileNotFoundError when no safetensors are found, ValueError for an unsupported model type."""
+    if isinstance(model_path, str):
+        model_name = model_path.lower().rstrip("/").split("/")[-1].split("-")
+        path = get_model_path(model_path)
+    elif isinstance(model_path, Path):
+        path = model_path
+        parts = path.parts
+        model_name = parts[parts.index("hub") + 1].lower().split("--")[-1].split("-") if "hub" in parts else path.name.lower().split("-")
+    else:
+        raise ValueError(f"Invalid model path type: {type(model_path)}")
+    config = load_config(path)
+    model_type = config.get("model_type") or (model_name[0] if model_name else None)
+    weight_files = glob.glob(str(path / "*.safetensors"))
+    if not weight_files:
+        logging.error(f"No safetensors found in {path}")
+        raise FileNotFoundError(f"No safetensors found in {path}")
+    arch, model_type = get_model_and_args(model_type, model_name)
+    from safetensors import safe_open
+
+    weights = {}
+    for wf in weight_files:
+        with safe_open(wf, framework="pt") as f:
+            for k in f.keys():
+                weights[k] = f.get_tensor(k)
+    if compute_dtype is None:
+        import torch
+
+        any_bf16 = any(getattr(v, "dtype", None) == torch.bfloat16 for v in weights.values())
+        compute_dtype = "bfloat16" if any_bf16 else "float32"  # the checkpoint dtype decides, as in the reference
+    cfg = arch.ModelConfig.from_dict(config)
+    model = arch.Model(cfg, compute_dtype=compute_dtype)
+    model.load_weights(weights, strict=strict)
+    return model

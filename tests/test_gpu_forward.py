@@ -337,3 +337,38 @@ def test_bf16_mode_tracks_fp32_oracle():
     for name in ("bert_dur", "d", "t_en", "dec_out"):
         for b in range(2):
             assert res[("mfma", name, b)] < 3.0 * res[("generic", name, b)] + 5e-3, (name, b, res[("mfma", name, b)], res[("generic", name, b)])
+
+
+def test_python_surface_load_model_pipeline_both_layouts(tmp_path):
+    """load_model() on a safetensors checkpoint in the PyTorch-side layout (what `sanitize` would convert) and in the
+    MLX-side layout give the same bits; KokoroPipeline.generate_from_tokens picks style row len(ps)-1 (pipeline.py:236)."""
+    from safetensors.numpy import save_file
+
+    from mlx_audio_amd.pipeline import KokoroPipeline
+    from mlx_audio_amd.utils import load_model
+
+    cfg = P.tiny_config()
+    cfg["vocab"] = P.load_vocab()
+    w = P.synth_checkpoint(cfg, 0)
+    outs = []
+    rows = np.load(os.path.join(GOLDEN, "af_heart_rows.npz"))["rows"]
+    pack = np.stack([rows[i % rows.shape[0]] for i in range(510)])[:, None, :]
+    np.save(tmp_path / "voice.npy", pack)
+    ps = "hɛlˈoʊ wˈɜɹld"
+    for name, ww in (("mlx", w), ("torch", P.to_torch_layout(w))):
+        d = tmp_path / f"kokoro-{name}"
+        d.mkdir()
+        json.dump(dict(cfg, model_type="kokoro"), open(d / "config.json", "w"))
+        save_file({k: np.ascontiguousarray(v) for k, v in ww.items()}, str(d / "model.safetensors"))
+        model = load_model(str(d))
+        pipe = KokoroPipeline(lang_code="a", model=model, repo_id="local")
+        model._seed = 41
+        res = list(pipe.generate_from_tokens(ps, voice=str(tmp_path / "voice.npy")))[0]
+        assert res.audio.shape[0] == 1 and res.audio.shape[1] == 600 * int(res.pred_dur.sum().item())
+        assert res.pred_dur.shape[0] == len([c for c in ps if c in cfg["vocab"]]) + 2
+        outs.append((res.audio.cpu().numpy(), res.pred_dur.cpu().numpy()))
+        # the style row is indexed by the phoneme-string length
+        o2 = model(ps, pack[len(ps) - 1], 1.0, return_output=True)
+        np.testing.assert_array_equal(o2.pred_dur.cpu().numpy(), outs[-1][1])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])

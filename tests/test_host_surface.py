@@ -1,0 +1,158 @@
+"""Host logic (no GPU): the mirrors of the reference's Python surface behave like the reference's own tests expect
+(mlx_audio/tts/tests/test_base.py:10-62, test_models.py:138-324) and the C-ABI library exports every declared symbol."""
+import ctypes
+import json
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import mlx_audio_amd.params as P
+from mlx_audio_amd import _lib
+from mlx_audio_amd.base import BaseModelArgs, check_array_shape
+from mlx_audio_amd.pipeline import ALIASES, LANG_CODES, KokoroPipeline, load_voice_tensor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "kokoro_hip.h")).read()
+    declared = set(re.findall(r"\b(kk_[a-z0-9_]+)\s*\(", hdr))
+    lib = _lib.load()
+    assert lib.kk_abi_version() == 1
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in kokoro_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= declared
+
+
+def test_kk_create_rejects_bad_configs_without_a_gpu():
+    from mlx_audio_amd.engine import make_kk_config
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = P.kokoro_config(with_vocab=False)
+    kc = make_kk_config(cfg)
+    assert lib.kk_create(ctypes.byref(kc), ctypes.byref(h)) == 0
+    # loading after create works on the host; an unknown dtype is refused with a message
+    arr = np.zeros((4,), np.float32)
+    shp = (ctypes.c_int64 * 1)(4)
+    assert lib.kk_load_tensor(h, b"x", 99, shp, 1, arr.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert b"dtype" in lib.kk_last_error()
+    assert lib.kk_workspace_bytes(h, 1, 10, 10) == 0  # not finalized
+    lib.kk_destroy(h)
+    kc.style_dim = 64
+    assert lib.kk_create(ctypes.byref(kc), ctypes.byref(h)) != 0
+    assert b"style_dim" in lib.kk_last_error()
+
+
+def test_base_model_args_from_dict():
+    class TestArgs(BaseModelArgs):
+        def __init__(self, param1, param2, param3=None):
+            self.param1, self.param2, self.param3 = param1, param2, param3
+
+    a = TestArgs.from_dict({"param1": 1, "param2": "test", "param3": True, "extra": "ignored"})
+    assert (a.param1, a.param2, a.param3) == (1, "test", True) and not hasattr(a, "extra")
+    assert TestArgs.from_dict({"param1": 1, "param2": "t"}).param3 is None
+
+
+def test_check_array_shape_truth_table():
+    assert check_array_shape(np.zeros((64, 3, 3)))
+    assert not check_array_shape(np.zeros((64, 3, 4)))
+    assert not check_array_shape(np.zeros((2, 3, 3)))
+    assert not check_array_shape(np.zeros((64, 3)))
+    assert not check_array_shape(np.zeros((64, 3, 3, 3)))
+
+
+def test_model_config_from_reference_hyperparameters():
+    from mlx_audio_amd.kokoro import Model, ModelConfig
+
+    cfg = P.kokoro_config()
+    cfg["vocab"] = {"a": 1, "b": 2}
+    mc = ModelConfig.from_dict(cfg)  # extra keys (model_type) are dropped
+    m = Model(mc)
+    assert m.vocab == {"a": 1, "b": 2} and m.sample_rate == 24000 and m.context_length == 512
+    out = Model.Output(audio="A", pred_dur="D")
+    assert out.audio == "A" and out.pred_dur == "D"
+    with pytest.raises(_lib.KokoroHipError):
+        m.engine  # no weights -> loud failure, never a fallback
+
+
+def test_aliases_and_quiet_pipeline():
+    for v in ALIASES.values():
+        assert v in LANG_CODES
+    assert ALIASES["en-us"] == "a" and LANG_CODES["j"] == "Japanese"
+    p = KokoroPipeline(lang_code="en-us", model=False, repo_id="mock")
+    assert p.lang_code == "a" and p.model is False
+    with pytest.raises(ValueError):
+        KokoroPipeline(lang_code="a", model=False, repo_id=None)
+    r = list(p.generate_from_tokens("hɛlˈoʊ", voice=None))
+    assert r[0].phonemes == "hɛlˈoʊ" and r[0].audio is None and len(r[0]) == 3 and list(r[0])[1] == "hɛlˈoʊ"
+    with pytest.raises(ValueError):
+        list(p.generate_from_tokens("a" * 511, voice=None))
+    with pytest.raises(ValueError):
+        list(KokoroPipeline(lang_code="a", model=object(), repo_id="m")("text", voice=None))
+
+
+def _tok(text, ph, ws=" "):
+    return SimpleNamespace(text=text, phonemes=ph, whitespace=ws, start_ts=None, end_ts=None)
+
+
+def test_chunker_and_timestamps():
+    toks = [_tok("Hello", "həlˈoʊ"), _tok(",", ",", " "), _tok("world", "wˈɜɹld", ""), _tok(".", ".", "")]
+    assert KokoroPipeline.tokens_to_ps(toks) == "həlˈoʊ , wˈɜɹld."
+    assert KokoroPipeline.tokens_to_text(toks) == "Hello , world."
+    p = KokoroPipeline(lang_code="a", model=False, repo_id="m")
+    # > 510 phonemes: split at the last sentence end (waterfall, pipeline.py:170-226)
+    long = []
+    for i in range(60):
+        long += [_tok("word", "wˈɜɹdwˈɜɹd"), _tok(".", ".", " ")]
+    chunks = list(p.en_tokenize(long))
+    assert len(chunks) >= 2 and all(len(ps) <= 510 for _, ps, _ in chunks)
+    assert "".join(ps.replace(" ", "") for _, ps, _ in chunks) == KokoroPipeline.tokens_to_ps(long).replace(" ", "")
+    assert chunks[0][1].endswith(".")
+    # timestamps: <bos>=5 frames, then tokens
+    toks = [_tok("hi", "hˈaɪ"), _tok("you", "jˈu", "")]
+    pred = np.array([5, 3, 3, 3, 2, 4, 4, 4, 6, 7], np.int32)  # bos | h ˈ a ɪ | space | j ˈ u | eos
+    KokoroPipeline.join_timestamps(toks, pred)
+    assert toks[0].start_ts == pytest.approx(2 * (5 - 3) / 80) and toks[0].end_ts > toks[0].start_ts
+    assert toks[1].start_ts >= toks[0].end_ts
+
+
+def test_voice_pack_formats(tmp_path):
+    rows = np.load(os.path.join(ROOT, "tests", "golden", "af_heart_rows.npz"))["rows"]
+    pack = np.repeat(rows[:1][None], 510, axis=0).reshape(510, 1, 256)
+    np.save(tmp_path / "v.npy", pack)
+    json.dump(pack[:4].tolist(), open(tmp_path / "v.json", "w"))
+    import torch
+
+    torch.save(torch.tensor(pack), tmp_path / "v.pt")
+    assert load_voice_tensor(str(tmp_path / "v.npy")).shape == (510, 1, 256)
+    assert load_voice_tensor(str(tmp_path / "v.json")).shape == (4, 1, 256)
+    np.testing.assert_array_equal(load_voice_tensor(str(tmp_path / "v.pt")), pack)
+    p = KokoroPipeline(lang_code="a", model=False, repo_id="m")
+    a = p.load_voice(str(tmp_path / "v.npy"))
+    both = p.load_voice(f"{tmp_path / 'v.npy'},{tmp_path / 'v.pt'}")
+    np.testing.assert_allclose(both, a)
+
+
+def test_load_model_error_behaviour(tmp_path):
+    from mlx_audio_amd.utils import load_model
+
+    d = tmp_path / "kokoro-82m"
+    d.mkdir()
+    with pytest.raises(FileNotFoundError):
+        load_model(str(d))  # no config.json
+    json.dump(dict(P.kokoro_config(), model_type="kokoro"), open(d / "config.json", "w"))
+    with pytest.raises(FileNotFoundError):
+        load_model(str(d))  # no safetensors (utils.py:195-215)
+    d2 = tmp_path / "bark-small"
+    d2.mkdir()
+    json.dump({"model_type": "bark"}, open(d2 / "config.json", "w"))
+    open(d2 / "x.safetensors", "wb").write(b"")
+    with pytest.raises(ValueError):
+        load_model(str(d2))  # unsupported model type (utils.py:116-119)
+    with pytest.raises(ValueError):
+        load_model(123)

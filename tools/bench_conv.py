@@ -1,0 +1,66 @@
+"""Micro-benchmark of the bf16 MFMA conv kernel on the shapes the Kokoro forward launches (B=32, F=650)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mlx_audio_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+SHAPES = [
+    # name, B, L, Cin, Cout, K, dil, residual
+    ("st1_k3", 32, 78001, 128, 128, 3, 1, True),
+    ("st1_k7_d3", 32, 78001, 128, 128, 7, 3, True),
+    ("st1_k11_d5", 32, 78001, 128, 128, 11, 5, True),
+    ("st0_k3", 32, 13000, 256, 256, 3, 1, True),
+    ("st0_k7", 32, 13000, 256, 256, 7, 1, True),
+    ("st0_k11_d5", 32, 13000, 256, 256, 11, 5, True),
+    ("dec_1152_1024_k3", 32, 650, 1152, 1024, 3, 1, False),
+    ("dec_1024_1024_k3", 32, 650, 1024, 1024, 3, 1, True),
+    ("albert_qkv", 32, 130, 768, 2304, 1, 1, False),
+    ("albert_ffn", 32, 130, 768, 2048, 1, 1, False),
+]
+
+
+def run(name, B, L, Cin, Cout, K, dil, res, iters=5):
+    CinP, CoutP = (Cin + 63) // 64 * 64, (Cout + 127) // 128 * 128
+    x = (torch.randn(B, L, CinP, device="cuda") * 1.0).to(torch.bfloat16)
+    w = (torch.randn(K, CoutP, CinP, device="cuda") / (K * Cin) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(CoutP, device="cuda")
+    out = torch.empty(B, L, Cout, device="cuda", dtype=torch.bfloat16)
+    r = torch.randn(B, L, Cout, device="cuda").to(torch.bfloat16) if res else None
+    pad = (K * dil - dil) // 2
+
+    def call():
+        rc = lib.kk_op_conv1d_bf16(st(), B, P(x), CinP, L, None, P(w), CinP, CoutP, P(bias), Cout, K, 0, 1, pad, dil, 0, 1.0, 0, 0.0, P(r), Cout,
+                                   1.0, 0, P(out), Cout, L, None, _lib.KK_BF16)
+        assert rc == 0, lib.kk_last_error()
+
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * B * L * Cin * Cout * K
+    by = B * L * (Cin + Cout * (2 if res else 1)) * 2
+    return {"name": name, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+
+
+if __name__ == "__main__":
+    sel = sys.argv[1:] or None
+    for s in SHAPES:
+        if sel and s[0] not in sel:
+            continue
+        print(json.dumps(run(*s)), flush=True)
