@@ -73,7 +73,11 @@ class Model:
     def load_weights(self, weights, strict: bool = True):
         """Accepts MLX-side or PyTorch-side names/layouts (what `sanitize`, kokoro.py:172-252, converts between)."""
         items = dict(weights.items() if hasattr(weights, "items") else weights)
-        self._engine = KokoroEngine(self._cfg_dict(), items, compute_dtype=self._compute_dtype)
+        cfg = self._cfg_dict()
+        g = items.get("decoder.encode.conv1.weight_g")  # width of the decoder blocks (1024 in Kokoro-82M, istftnet.py:917)
+        if g is not None:
+            cfg["decoder_hidden"] = int(g.shape[0])
+        self._engine = KokoroEngine(cfg, items, compute_dtype=self._compute_dtype)
         return self
 
     def sanitize(self, weights):
