@@ -144,7 +144,7 @@ int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channel
 int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
 int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
 void kk_debug_clear(kk_model* m);
-void kk_debug_force_generic(kk_model* m, int on); /* bf16 mode without the MFMA kernel (A/B tests) */
+void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention

@@ -100,8 +100,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
     // sunk towards their use.
     const int lin_hi = Lin > 0 ? Lin - 1 : 0;
     unsigned xok = 0;
+    float4 nA[2], nB[2], nAl[2];  // fused AdaIN parameters of this thread's 8 channels of the slab
+    const bool has_nrm = a.nrm_a != nullptr;
     auto load_x = [&](int chunk) {
       xok = 0;
+      if (has_nrm) {
+        const int c = chunk * CK + (tid & 7) * 8;  // (id & 7) == (tid & 7): 256 is a multiple of 8
+        const float* pa = a.nrm_a + (long long)b * a.nrm_stride + c;
+        const float* pb = a.nrm_b + (long long)b * a.nrm_stride + c;
+        nA[0] = *(const float4*)pa; nA[1] = *(const float4*)(pa + 4);
+        nB[0] = *(const float4*)pb; nB[1] = *(const float4*)(pb + 4);
+        if (a.nrm_act == KK_ACT_SNAKE) {
+          float al[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) al[k] = (c + k) < a.nrm_C ? a.nrm_alpha[c + k] : 1.0f;
+          nAl[0] = make_float4(al[0], al[1], al[2], al[3]);
+          nAl[1] = make_float4(al[4], al[5], al[6], al[7]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int id = i * 256 + tid;
@@ -123,7 +139,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
         if (r < xrows) {
           U16 t;
           const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
-          t.u = make_uint4(xreg[i].x & msk, xreg[i].y & msk, xreg[i].z & msk, xreg[i].w & msk);
+          t.u = xreg[i];
+          if (has_nrm) {  // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging
+            const float pa[8] = {nA[0].x, nA[0].y, nA[0].z, nA[0].w, nA[1].x, nA[1].y, nA[1].z, nA[1].w};
+            const float pb[8] = {nB[0].x, nB[0].y, nB[0].z, nB[0].w, nB[1].x, nB[1].y, nB[1].z, nB[1].w};
+            const float pl[8] = {nAl[0].x, nAl[0].y, nAl[0].z, nAl[0].w, nAl[1].x, nAl[1].y, nAl[1].z, nAl[1].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float y = __builtin_fmaf((float)t.h[k], pa[k], pb[k]);
+              if (a.nrm_act == KK_ACT_SNAKE) {
+                const float sn = __sinf(pl[k] * y);
+                y = y + __builtin_amdgcn_rcpf(pl[k]) * (sn * sn);
+              } else if (a.nrm_act == KK_ACT_LRELU) {
+                y = y > 0.f ? y : y * a.nrm_slope;
+              }
+              t.h[k] = (bf16_t)y;
+            }
+          }
+          t.u = make_uint4(t.u.x & msk, t.u.y & msk, t.u.z & msk, t.u.w & msk);  // padding rows stay exactly zero
           if (a.in_slope != 1.0f) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -226,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
   const int n = n0 + (tid & 15) * 8;  // this thread's 8 output channels (same for all its rows)
   const int lo_hi = a.Lo_rows - 1;
   constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
+  float st_s[8], st_q[8];  // column sums / sums of squares of the values this thread stores
+#pragma unroll
+  for (int k = 0; k < 8; ++k) st_s[k] = st_q[k] = 0.f;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     int opv[4];
@@ -307,11 +343,47 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
           *(uint4*)dst = t.u;
+          if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float r = (float)t.h[k];
+              st_s[k] += r;
+              st_q[k] = __builtin_fmaf(r, r, st_q[k]);
+            }
+          }
         } else {
           *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
       }
+    }
+  }
+  if (a.stat_part) {
+    // rows of one column group live in threads tid = rg*16 + cg: reduce rg over the wave by shuffles (xor 16, 32),
+    // then over the 4 waves through LDS; one deterministic partial per (utterance, tile, column)
+    __syncthreads();  // every wave is done reading the Cs tile
+    float* red = (float*)smem;  // [4 waves][2][128]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      st_s[k] += __shfl_xor(st_s[k], 16);
+      st_s[k] += __shfl_xor(st_s[k], 32);
+      st_q[k] += __shfl_xor(st_q[k], 16);
+      st_q[k] += __shfl_xor(st_q[k], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(wave * 2 + 0) * 128 + lane * 8 + k] = st_s[k];
+        red[(wave * 2 + 1) * 128 + lane * 8 + k] = st_q[k];
+      }
+    }
+    __syncthreads();
+    const int which = tid >> 7, col = tid & 127;  // threads 0..127 -> sums, 128..255 -> sums of squares
+    if (n0 + col < a.Cout) {
+      const float v = red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col] + red[(2 * 2 + which) * 128 + col] +
+                      red[(3 * 2 + which) * 128 + col];
+      const int tile = blockIdx.x * nphase + phase;
+      a.stat_part[(((long long)b * a.stat_ntiles + tile) * 2 + which) * a.Cout + n0 + col] = v;
     }
   }
 }

@@ -27,12 +27,30 @@ struct KKMfmaArgs {
   int accumulate, act;
   float act_slope;
   int dbg;  // timing experiments only (KK_MFMA_DBG): bit0 skip W reloads, bit1 skip X reloads
+  // fused input transform (AdaIN apply + activation while staging X):  y = act(x * nrm_a[b][c] + nrm_b[b][c])
+  const float* nrm_a;  // [B][nrm_stride], zero for pad channels; null = no transform
+  const float* nrm_b;
+  int nrm_stride;
+  int nrm_act;            // KK_ACT_NONE / LRELU / SNAKE
+  float nrm_slope;
+  const float* nrm_alpha; // [nrm_C] Snake alpha
+  int nrm_C;
+  // fused output statistics: per-tile column sums of the STORED values, part[((b*stat_ntiles + tile)*2 + {0,1})*Cout + n]
+  float* stat_part;
+  int stat_ntiles;
 };
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
 
 // ---- normalisation family (kk_norm.hip)
 struct KKStatsArgs {
+  // optional AdaIN folding: pa = rstd*(1+gamma), pb = beta - mean*pa  (gamma/beta from the style projection gb)
+  const float* gb;
+  int gbs;
+  float* pa;
+  float* pb;
+  int pstride, Cp;  // pa/pb row pitch and number of channels written (pads get 0)
+  int fused;        // 1: `partial` holds un-shifted per-tile sums written by conv epilogues (sum ALL nchunk tiles)
   const void* x;
   long long xbs;
   int ldx;
@@ -48,6 +66,7 @@ struct KKStatsArgs {
 };
 size_t kk_stats_partial_floats(int B, int C, int Lmax, int rows_per_chunk);
 int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st);
+int kk_launch_norm_finalize(KKStatsArgs a, int B, hipStream_t st);  // fused partials -> mean/rstd (+ pa/pb)
 
 struct KKAdainArgs {
   const void* x;

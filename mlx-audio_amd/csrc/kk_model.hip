@@ -137,6 +137,7 @@ struct kk_model {
 
   // optional per-kernel-class timing (kk_profile_*): HIP events around every launch of a class
   bool force_generic = false;  // tests: run the bf16 mode without the MFMA kernel
+  bool no_fusion = false;      // tests: MFMA convs but stand-alone statistics / AdaIN kernels
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs
   struct ProfRec { int cls; double flops; double bytes; };
@@ -657,6 +658,14 @@ struct ConvOpt {
   float scale = 1.f;
   int accumulate = 0;
   const Buf* res = nullptr;
+  // MFMA-only fusions (bf16 mode): AdaIN + activation applied while the input is staged; statistics of the output
+  const float* nrm_a = nullptr;
+  const float* nrm_b = nullptr;
+  int nrm_act = KK_ACT_NONE;
+  float nrm_slope = 0.f;
+  const float* nrm_alpha = nullptr;
+  int nrm_C = 0;
+  bool want_stats = false;
 };
 
 struct Ctx {
@@ -729,12 +738,17 @@ struct Ctx {
     const double flops = 2.0 * B * rows_out * w.Cout * w.Cin * taps;
     const double bytes = B * (rows_out * w.Cout * esz(out.dtype) * (o.res ? 2.0 : 1.0) + (double)Q * (o.mode == KK_CONVT ? 1 : o.stride) * w.Cin * esz(x.dtype)) +
                          (double)w.Kw * w.Cin * w.Cout * 4.0;
-    const bool al16 = !(((uintptr_t)x.p | (uintptr_t)out.p | (uintptr_t)(o.res ? o.res->p : nullptr)) & 15);
-    if (w.mfma && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
-        kk_mfma_eligible(w.Cin, w.Cout, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
-        (!o.res || o.res->ld % 8 == 0) && al16 && !m->force_generic) {
+    if (can_mfma(w, x, out, o)) {
       KKMfmaArgs g;
       memset(&g, 0, sizeof g);
+      g.nrm_a = o.nrm_a; g.nrm_b = o.nrm_b; g.nrm_stride = fz_stride; g.nrm_act = o.nrm_act; g.nrm_slope = o.nrm_slope;
+      g.nrm_alpha = o.nrm_alpha; g.nrm_C = o.nrm_C;
+      if (o.want_stats) {
+        last_ntiles = kk_cdiv(Q, 128) * (o.mode == KK_CONVT ? o.stride : 1);
+        if ((size_t)B * last_ntiles * 2 * w.Cout > fz_part_floats) return kk_fail("internal: statistics scratch too small");
+        g.stat_part = fz_part;
+        g.stat_ntiles = last_ntiles;
+      }
       g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
       g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
       if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
@@ -746,11 +760,53 @@ struct Ctx {
       prof_stop(1, flops, bytes);
       return rc;
     }
+    if (o.nrm_a || o.want_stats) return kk_fail("internal: fused norm requested on a conv that is not MFMA eligible");
     prof_start();
     const int rc = kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
     prof_stop(0, flops, bytes);
     return rc;
   }
+
+  bool can_mfma(const ConvW& w, const Buf& x, const Buf& out, const ConvOpt& o) const {
+    const bool al16 = !(((uintptr_t)x.p | (uintptr_t)out.p | (uintptr_t)(o.res ? o.res->p : nullptr)) & 15);
+    return w.mfma && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
+           kk_mfma_eligible(w.Cin, w.Cout, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
+           (!o.res || o.res->ld % 8 == 0) && al16 && !m->force_generic;
+  }
+
+  // ---- fused-norm plumbing (bf16 MFMA path) ------------------------------------------------------------------
+  float* fz_part = nullptr;      // per-tile column sums written by conv epilogues
+  size_t fz_part_floats = 0;
+  float* fz_pa[2] = {nullptr, nullptr};  // ping-pong folded AdaIN parameters [B][fz_stride]
+  float* fz_pb[2] = {nullptr, nullptr};
+  int fz_stride = 0;
+  int fz_flip = 0;
+  int last_ntiles = 0;
+  // partial sums of the last want_stats conv -> mean/rstd (optional) and folded parameters for the AdaIN `gb`
+  int finalize(int C, KKLen len, const float* gb, int gbs, float* mean, float* rstd, float** pa, float** pb) {
+    if (dry) return 0;
+    KKStatsArgs a;
+    memset(&a, 0, sizeof a);
+    a.C = C; a.len = len; a.partial = fz_part; a.nchunk = last_ntiles; a.mean = mean; a.rstd = rstd; a.eps = 1e-5f; a.fused = 1;
+    if (gb) {
+      fz_flip ^= 1;
+      a.gb = gb; a.gbs = gbs; a.pa = fz_pa[fz_flip]; a.pb = fz_pb[fz_flip]; a.pstride = fz_stride; a.Cp = rup64(C);
+      *pa = a.pa; *pb = a.pb;
+    }
+    return kk_launch_norm_finalize(a, B, st);
+  }
+  // known mean/rstd (standalone statistics kernel or a kept copy) -> folded parameters
+  int fold(int C, KKLen len, const float* mean, const float* rstd, const float* gb, int gbs, float** pa, float** pb) {
+    if (dry) return 0;
+    KKStatsArgs a;
+    memset(&a, 0, sizeof a);
+    fz_flip ^= 1;
+    a.C = C; a.len = len; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.fused = 2; a.gb = gb; a.gbs = gbs;
+    a.pa = fz_pa[fz_flip]; a.pb = fz_pb[fz_flip]; a.pstride = fz_stride; a.Cp = rup64(C);
+    *pa = a.pa; *pb = a.pb;
+    return kk_launch_norm_finalize(a, B, st);
+  }
+  static int rup64(int v) { return (v + 63) / 64 * 64; }
 
   // scratch for instance-norm statistics, sized for the largest request seen in the dry run
   float* st_partial = nullptr;
@@ -822,6 +878,43 @@ int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in
   const int Lmax_out = r.up ? 2 * Lmax_in : Lmax_in;
   KKLen lout = lin;
   if (r.up) { lout.mul = lin.mul * 2; lout.add = lin.add * 2; }
+  {
+    // bf16 MFMA path: AdaIN + LeakyReLU ride in the convs' input staging, statistics in their epilogues
+    ConvOpt p1, p2;
+    p1.pad = p2.pad = 1;
+    p2.res = r.learned ? &out : &x;
+    const Buf& c1in = r.up ? bufA : x;
+    if (c.adt == KK_BF16 && c.fz_part && !c.m->no_fusion && c.can_mfma(r.conv1, c1in, bufB, p1) && c.can_mfma(r.conv2, bufB, out, p2) &&
+        (!r.learned || c.can_mfma(r.sc, x, out, ConvOpt()))) {
+      float *pa = nullptr, *pb = nullptr;
+      KK_TRY(c.stats(x, r.Cin, Lmax_in, lin));
+      ConvOpt o1;
+      o1.pad = 1;
+      o1.want_stats = true;
+      if (r.up) {
+        KK_TRY(c.adain(x, r.Cin, lin, bufA, rup(r.Cin, 64) <= bufA.ld ? rup(r.Cin, 64) : r.Cin, Lmax_out, style + r.n1.off, gbs,
+                       KK_ACT_LRELU, 0.2f, nullptr, 1, r.pool_w.p, r.pool_b.p));
+      } else {
+        KK_TRY(c.fold(r.Cin, lin, c.st_mean, c.st_rstd, style + r.n1.off, gbs, &pa, &pb));
+        o1.nrm_a = pa; o1.nrm_b = pb; o1.nrm_act = KK_ACT_LRELU; o1.nrm_slope = 0.2f; o1.nrm_C = r.Cin;
+      }
+      KK_TRY(c.conv(r.conv1, c1in, lout, bufB, lout, Lmax_out, o1));
+      KK_TRY(c.finalize(r.Cout, lout, style + r.n2.off, gbs, nullptr, nullptr, &pa, &pb));
+      ConvOpt o2;
+      o2.pad = 1;
+      o2.scale = 0.70710678118654752440f;
+      o2.nrm_a = pa; o2.nrm_b = pb; o2.nrm_act = KK_ACT_LRELU; o2.nrm_slope = 0.2f; o2.nrm_C = r.Cout;
+      if (r.learned) {
+        ConvOpt os;
+        os.in_shift = r.up ? 1 : 0;
+        KK_TRY(c.conv(r.sc, x, lin, out, lout, Lmax_out, os));
+        o2.res = &out;
+      } else {
+        o2.res = &x;
+      }
+      return c.conv(r.conv2, bufB, lout, out, lout, Lmax_out, o2);
+    }
+  }
   KK_TRY(c.stats(x, r.Cin, Lmax_in, lin));
   KK_TRY(c.adain(x, r.Cin, lin, bufA, rup(r.Cin, 64) <= bufA.ld ? rup(r.Cin, 64) : r.Cin, Lmax_out, style + r.n1.off, gbs, KK_ACT_LRELU,
                  0.2f, nullptr, r.up ? 1 : 0, r.pool_w.p, r.pool_b.p));
@@ -848,7 +941,43 @@ int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in
 // AdaINResBlock1 (istftnet.py:377-396).  Iteration 0 reads x_in; iterations keep their running value in y.
 // If acc != null the last iteration writes acc (+)= (conv + y) * acc_scale instead of y.
 int run_resblock1(Ctx& c, const ResBlock1& r, const Buf& x_in, const Buf& y, Buf& t1, Buf& t2, int Lmax, KKLen len, const float* style,
-                  int gbs, const Buf* acc, float acc_scale, int acc_accumulate) {
+                  int gbs, const Buf* acc, float acc_scale, int acc_accumulate, bool x_stats_ready = false) {
+  {
+    ConvOpt p1, p2;
+    p1.dil = r.dil[2]; p1.pad = (r.k * r.dil[2] - r.dil[2]) / 2;
+    p2.pad = (r.k - 1) / 2; p2.res = &x_in;
+    if (c.adt == KK_BF16 && c.fz_part && !c.m->no_fusion && c.can_mfma(r.c1[0], x_in, t2, p1) && c.can_mfma(r.c2[0], t2, y, p2) &&
+        (!acc || c.can_mfma(r.c2[2], t2, *acc, p2))) {
+      // bf16 MFMA path: 2 convs + 2 tiny parameter folds per iteration, 5 tensor passes instead of 12
+      float *pa = nullptr, *pb = nullptr;
+      if (!x_stats_ready) KK_TRY(c.stats(x_in, r.C, Lmax, len));
+      KK_TRY(c.fold(r.C, len, c.st_mean, c.st_rstd, style + r.a1[0].off, gbs, &pa, &pb));
+      for (int j = 0; j < 3; ++j) {
+        const Buf& src = j == 0 ? x_in : y;
+        ConvOpt o1;
+        o1.dil = r.dil[j];
+        o1.pad = (r.k * r.dil[j] - r.dil[j]) / 2;
+        o1.nrm_a = pa; o1.nrm_b = pb; o1.nrm_act = KK_ACT_SNAKE; o1.nrm_alpha = r.al1[j].p; o1.nrm_C = r.C;
+        o1.want_stats = true;
+        KK_TRY(c.conv(r.c1[j], src, len, t2, len, Lmax, o1));
+        KK_TRY(c.finalize(r.C, len, style + r.a2[j].off, gbs, nullptr, nullptr, &pa, &pb));
+        ConvOpt o2;
+        o2.pad = (r.k - 1) / 2;
+        o2.res = &src;
+        o2.nrm_a = pa; o2.nrm_b = pb; o2.nrm_act = KK_ACT_SNAKE; o2.nrm_alpha = r.al2[j].p; o2.nrm_C = r.C;
+        if (j == 2 && acc) {
+          o2.scale = acc_scale;
+          o2.accumulate = acc_accumulate;
+          KK_TRY(c.conv(r.c2[j], t2, len, *acc, len, Lmax, o2));
+        } else {
+          o2.want_stats = j < 2;
+          KK_TRY(c.conv(r.c2[j], t2, len, y, len, Lmax, o2));
+          if (j < 2) KK_TRY(c.finalize(r.C, len, style + r.a1[j + 1].off, gbs, nullptr, nullptr, &pa, &pb));
+        }
+      }
+      return 0;
+    }
+  }
   for (int j = 0; j < 3; ++j) {
     const Buf& src = j == 0 ? x_in : y;
     KK_TRY(c.stats(src, r.C, Lmax, len));
@@ -1011,6 +1140,17 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     c.st_partial = c.f32(pmax);
     c.st_mean = c.f32(cmax);
     c.st_rstd = c.f32(cmax);
+    // fused-norm scratch of the bf16 MFMA path
+    c.fz_stride = rup(std::max(std::max(DH + 2 + 64, H + S), C0), 64);
+    const size_t tiles = std::max(std::max((size_t)kk_cdiv(Tf, 128) * (C0 / 4), (size_t)kk_cdiv(L20, 128) * (C0 / 2)),
+                                  (size_t)kk_cdiv(L2, 128) * std::max(DH, H));
+    c.fz_part_floats = (size_t)B * tiles * 2;
+    float* fp = c.f32(c.fz_part_floats);
+    float* p0 = c.f32((size_t)B * c.fz_stride);
+    float* p1 = c.f32((size_t)B * c.fz_stride);
+    float* p2 = c.f32((size_t)B * c.fz_stride);
+    float* p3 = c.f32((size_t)B * c.fz_stride);
+    if (c.adt == KK_BF16) { c.fz_part = fp; c.fz_pa[0] = p0; c.fz_pb[0] = p1; c.fz_pa[1] = p2; c.fz_pb[1] = p3; }
   }
   // ---- F0Ntrain (modules.py:355-377)
   float* xprojF = c.f32((size_t)B * Fmax * 4 * H);
@@ -1118,7 +1258,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     }
     KK_TRY(c.dbg(i == 0 ? "gen_pre_res0" : "gen_pre_res1", xi, Cst));
     for (int j = 0; j < nk; ++j)
-      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0));
+      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0, j > 0));
     KK_TRY(c.dbg(i == 0 ? "gen_stage0" : "gen_stage1", accb, Cst));
     cur = accb;
     lcur = lst;
@@ -1337,7 +1477,9 @@ extern "C" int kk_debug_override(kk_model* m, const char* name, const float* src
   return 0;
 }
 extern "C" void kk_debug_force_generic(kk_model* m, int on) {
-  if (m) m->force_generic = on != 0;
+  if (!m) return;
+  m->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
+  m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
 }
 extern "C" void kk_debug_clear(kk_model* m) {
   if (!m) return;

@@ -54,26 +54,43 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(KKStatsArgs a, int c
 template <typename T>
 __global__ __launch_bounds__(256) void stats_final_kernel(KKStatsArgs a) {
   const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (c >= a.C) return;
+  if (c >= a.C) {
+    if (a.pa && c < a.Cp) {  // pad channels: transform to exactly zero
+      a.pa[(long long)b * a.pstride + c] = 0.f;
+      a.pb[(long long)b * a.pstride + c] = 0.f;
+    }
+    return;
+  }
   const int L = kk_len(a.len, b);
   float mean = 0.f, rstd = 0.f;
-  if (L > 0) {
-    const int nch = kk_cdiv(L, a.rows_per_chunk);
+  if (a.fused == 2) {  // statistics already known: only fold them with this layer's gamma / beta
+    mean = a.mean[(long long)b * a.C + c];
+    rstd = a.rstd[(long long)b * a.C + c];
+  } else if (L > 0) {
+    const int nch = a.fused ? a.nchunk : kk_cdiv(L, a.rows_per_chunk);
     double S = 0.0, SS = 0.0;
     const float* pb = a.partial + (long long)b * a.nchunk * 2 * a.C;
     for (int k = 0; k < nch; ++k) {
       S += (double)pb[(long long)k * 2 * a.C + c];
       SS += (double)pb[(long long)k * 2 * a.C + a.C + c];
     }
-    const double shift = (double)kk_ld((const T*)a.x + (long long)b * a.xbs + c);
+    const double shift = a.fused ? 0.0 : (double)kk_ld((const T*)a.x + (long long)b * a.xbs + c);
     const double m = S / L;
     double var = SS / L - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)(shift + m);
     rstd = (float)(1.0 / sqrt(var + (double)a.eps));
   }
-  a.mean[(long long)b * a.C + c] = mean;
-  a.rstd[(long long)b * a.C + c] = rstd;
+  if (a.fused != 2) {
+    if (a.mean) a.mean[(long long)b * a.C + c] = mean;
+    if (a.rstd) a.rstd[(long long)b * a.C + c] = rstd;
+  }
+  if (a.pa) {
+    const float g = 1.0f + a.gb[(long long)b * a.gbs + c], be = a.gb[(long long)b * a.gbs + a.C + c];
+    const float A = rstd * g;
+    a.pa[(long long)b * a.pstride + c] = A;
+    a.pb[(long long)b * a.pstride + c] = be - mean * A;
+  }
 }
 
 // ---------------------------------------------------------------- AdaIN apply (+ act, + pool)
@@ -213,7 +230,8 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
   a.nchunk = kk_cdiv(a.Lmax, a.rows_per_chunk);
   if (a.nchunk <= 0) a.nchunk = 1;
   const int cw = a.C >= 256 ? 256 : (a.C > 64 ? 128 : 64);
-  dim3 g1(a.nchunk, B), g2(kk_cdiv(a.C, 256), B);
+  a.fused = 0;
+  dim3 g1(a.nchunk, B), g2(kk_cdiv(a.pa && a.Cp > a.C ? a.Cp : a.C, 256), B);
   if (dtype == KK_F32) {
     hipLaunchKernelGGL(stats_partial_kernel<float>, g1, dim3(256), 0, st, a, cw);
     hipLaunchKernelGGL(stats_final_kernel<float>, g2, dim3(256), 0, st, a);
@@ -221,6 +239,15 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
     hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, a, cw);
     hipLaunchKernelGGL(stats_final_kernel<bf16_t>, g2, dim3(256), 0, st, a);
   }
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
+int kk_launch_norm_finalize(KKStatsArgs a, int B, hipStream_t st) {
+  if (B <= 0 || a.C <= 0) return 0;
+  if (a.fused != 2) a.fused = 1;
+  const int cover = a.pa ? (a.Cp > a.C ? a.Cp : a.C) : a.C;
+  hipLaunchKernelGGL(stats_final_kernel<float>, dim3(kk_cdiv(cover, 256), B), dim3(256), 0, st, a);
   KK_CHECK_LAUNCH();
   return 0;
 }
