@@ -1,22 +1,28 @@
 // bf16 MFMA implicit-GEMM convolution for frames-major tensors (gfx950, v_mfma_f32_32x32x16_bf16).
 //
-//   out[b][q][n] = sum_t sum_ci  W[t][n][ci] * X[b][q + off_t][ci]       (stride 1, any dilation)
+//   out[b][q][n] = sum_t sum_ci  W[t][n][ci] * f(X[b][q + off_t][ci])       (stride 1, any dilation)
 //   transposed conv = `stride` independent phase convolutions with 2 taps each (polyphase form, see kk_conv.hip)
+//   f = identity, LeakyReLU, or the fused AdaIN apply + Snake / LeakyReLU of the reference's resblocks
 //
-// GEMM view per workgroup: M = 128 output rows, N = 128 output channels, K = taps x Cin walked in slabs of 64
-// channels.  A = X rows (positions), B = W rows (output channels); both are k-contiguous in LDS so a lane's MFMA
-// fragment (8 consecutive k) is ONE ds_read_b128.  LDS rows are padded 128 B -> 144 B: 16 consecutive rows then start
-// on 16 distinct 4-bank groups, which makes the b128 fragment reads conflict-free (banks = (addr/4) % 64).
+// GEMM view per workgroup: M = BM output rows (128 or 256), N = 128 output channels, K = taps x Cin walked in slabs of
+// 64 channels.  A = X rows (positions), B = W rows (output channels); both are k-contiguous in LDS so a lane's MFMA
+// fragment (8 consecutive k) is ONE ds_read_b128.  LDS rows are padded 128 B -> 144 B: 16 consecutive rows start on 16
+// distinct 4-bank groups, so the b128 fragment reads are conflict-free (banks = (addr/4) % 64).
 //
-//   * the X slab [128 + halo rows][64 ch] is loaded once per channel slab and re-used by every tap as a shifted window
-//   * W tiles [128 n][64 ci] are double-buffered in LDS and prefetched through registers one tap ahead, so the
-//     global (L2-resident) weight loads run under the 16 MFMAs per wave of the current tap: one barrier per tap
-//   * 4 waves as 2 x 2, each 64 x 64 outputs = 2 x 2 accumulators of 32 x 32 (64 acc VGPRs)
-//   * epilogue through LDS (fp32 tile) so bias / activation / residual / scale / accumulate / length mask are applied
-//     on coalesced 16-byte rows and the result is rounded to bf16 exactly once.
-#include "kk_common.h"
+//   * 4 waves as 2 x 2; a wave owns WM x 64 outputs (WM = 64 or 128) = (WM/32) x 2 accumulators of 32 x 32.  WM = 128
+//     re-uses every B (weight) fragment for 4 row tiles: 6 ds_read_b128 per 8 MFMAs instead of 4 per 4 -- with two
+//     workgroups per CU the 64-row variant saturates the LDS read port (1 b128 read per MFMA and wave = 256 B/clk/CU),
+//     and it halves the L2 traffic for W per MFMA.
+//   * the X slab [BM + halo rows][64 ch] is loaded once per channel slab (register prefetch issued at the first tap of
+//     the previous slab) and re-used by every tap as a shifted window
+//   * W tiles [128 n][64 ci] are double-buffered in LDS and prefetched through registers one tap ahead: one barrier per tap
+//   * all global loads are unconditional (clamped address + mask at use): a load under a data-dependent branch makes
+//     hipcc wait vmcnt(0) right behind it, which serialises the loads (one HBM round trip each)
+//   * epilogue through a 128 x 128 fp32 LDS tile per 128 rows: bias / activation / residual / scale / accumulate / length
+//     mask on coalesced 16-byte rows, ONE rounding to bf16, optional per-tile column sums for the next instance norm.
 #include <stdlib.h>
 
+#include "kk_common.h"
 #include "kk_kernels.h"
 
 namespace {
@@ -24,17 +30,22 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, CK = 64;
-constexpr int XLD = CK + 8;        // elements per LDS row (144 B)
-constexpr int MAX_HALO = 64;       // (Kw-1)*dil <= 50 on this path
-constexpr int XROWS = BM + MAX_HALO;
-constexpr int CLD = BN;            // fp32 epilogue tile pitch (128 x 128 x 4 B = exactly 64 KiB)
+constexpr int BN = 128, CK = 64;
+constexpr int XLD = CK + 8;   // elements per LDS row (144 B)
+constexpr int MAX_HALO = 50;  // (Kw-1)*dil of the largest resblock conv (k 11, dilation 5)
+constexpr int CLD = BN;       // fp32 epilogue tile pitch: 128 x 128 x 4 B = exactly 64 KiB
+constexpr int WS_BYTES = BN * XLD * 2;    // 18432 per buffer
+constexpr int PS_BYTES = 2 * 3 * CK * 4;  // double-buffered AdaIN parameter table of one slab (A, B, alpha)
 
-constexpr int XS_BYTES = XROWS * XLD * 2;          // 27648
-constexpr int WS_BYTES = BN * XLD * 2;             // 18432 per buffer
-constexpr int MAIN_BYTES = XS_BYTES + 2 * WS_BYTES;  // 64512
-constexpr int EPI_BYTES = BM * CLD * 4;            // 67584
-constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+template <int BM>
+struct Geo {
+  static constexpr int XROWS = BM + MAX_HALO;
+  static constexpr int XS_BYTES = XROWS * XLD * 2;
+  static constexpr int MAIN_BYTES = XS_BYTES + 2 * WS_BYTES + PS_BYTES;
+  static constexpr int EPI_BYTES = 128 * CLD * 4;
+  static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  static constexpr int XREG = (XROWS * 8 + 255) / 256;  // 16-byte chunks of the slab per thread
+};
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -47,12 +58,16 @@ union U32x8 {
   float f[8];
 };
 
-template <typename TO>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
+template <typename TO, int WM, bool NRM>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma_kernel(KKMfmaArgs a) {
+  constexpr int BM = 2 * WM, MI = WM / 32;
+  using G = Geo<BM>;
+  constexpr int XREG = G::XREG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Xs = (bf16_t*)smem;
-  bf16_t* Ws0 = (bf16_t*)(smem + XS_BYTES);
-  bf16_t* Ws1 = (bf16_t*)(smem + XS_BYTES + WS_BYTES);
+  bf16_t* Ws0 = (bf16_t*)(smem + G::XS_BYTES);
+  bf16_t* Ws1 = (bf16_t*)(smem + G::XS_BYTES + WS_BYTES);
+  float* Ps = (float*)(smem + G::XS_BYTES + 2 * WS_BYTES);  // [2][3][64]
   float* Cs = (float*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
   const int op_first = a.mode == KK_CONV ? q0 : phase + a.stride * q0;
   const bool tile_live = op_first < Lout;  // uniform over the workgroup
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -90,36 +105,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
     const bf16_t* xb = a.x + (long long)b * a.xbs;
     const int nchunk = a.CinP / CK;
     const int nit = nchunk * ntaps;
-
-    // ---- loaders (global -> registers) --------------------------------------------------------------
-    uint4 xreg[6];  // up to 192 rows x 8 chunks of 16 B = 1536 chunks / 256 threads
-    uint4 wreg[4];  // 128 rows x 8 chunks = 1024 chunks / 256 threads
-    // Unconditional loads from clamped addresses; validity is applied when the registers are written to LDS.  A load under
-    // a data-dependent branch (or a select the optimiser turns into one) makes hipcc wait vmcnt(0) right behind it, which
-    // serialises the six loads (one HBM round trip each); the empty asm with a memory clobber keeps the loads from being
-    // sunk towards their use.
     const int lin_hi = Lin > 0 ? Lin - 1 : 0;
+
+    uint4 xreg[XREG];
+    float4 preg = make_float4(0.f, 0.f, 0.f, 0.f);  // threads 0..47: one float4 of the slab's A | B | alpha
     unsigned xok = 0;
-    float4 nA[2], nB[2], nAl[2];  // fused AdaIN parameters of this thread's 8 channels of the slab
-    const bool has_nrm = a.nrm_a != nullptr;
-    auto load_x = [&](int chunk) {
+
+    auto load_x = [&](int chunk) __attribute__((always_inline)) {
       xok = 0;
-      if (has_nrm) {
-        const int c = chunk * CK + (tid & 7) * 8;  // (id & 7) == (tid & 7): 256 is a multiple of 8
-        const float* pa = a.nrm_a + (long long)b * a.nrm_stride + c;
-        const float* pb = a.nrm_b + (long long)b * a.nrm_stride + c;
-        nA[0] = *(const float4*)pa; nA[1] = *(const float4*)(pa + 4);
-        nB[0] = *(const float4*)pb; nB[1] = *(const float4*)(pb + 4);
-        if (a.nrm_act == KK_ACT_SNAKE) {
-          float al[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) al[k] = (c + k) < a.nrm_C ? a.nrm_alpha[c + k] : 1.0f;
-          nAl[0] = make_float4(al[0], al[1], al[2], al[3]);
-          nAl[1] = make_float4(al[4], al[5], al[6], al[7]);
+      // parameter loads go FIRST: vmcnt retires in order, so storing them to LDS one tap later does not wait for the slab
+      if (NRM && tid < 48) {
+        const int which = tid >> 4, c = chunk * CK + (tid & 15) * 4;
+        if (which == 0) preg = *(const float4*)(a.nrm_a + (long long)b * a.nrm_stride + c);
+        else if (which == 1) preg = *(const float4*)(a.nrm_b + (long long)b * a.nrm_stride + c);
+        else if (a.nrm_act == KK_ACT_SNAKE) {
+          preg.x = (c + 0) < a.nrm_C ? a.nrm_alpha[c + 0] : 1.0f;
+          preg.y = (c + 1) < a.nrm_C ? a.nrm_alpha[c + 1] : 1.0f;
+          preg.z = (c + 2) < a.nrm_C ? a.nrm_alpha[c + 2] : 1.0f;
+          preg.w = (c + 3) < a.nrm_C ? a.nrm_alpha[c + 3] : 1.0f;
         }
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < XREG; ++i) {
         const int id = i * 256 + tid;
         const int r = id >> 3, c8 = (id & 7) * 8;
         int row = q0 + min_off + r;
@@ -131,19 +138,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
       }
       asm volatile("" ::: "memory");
     };
-    auto store_x = [&]() {
+    auto store_p = [&](int chunk) __attribute__((always_inline)) {
+      if (NRM && tid < 48) *(float4*)(Ps + (chunk & 1) * 3 * CK + (tid >> 4) * CK + (tid & 15) * 4) = preg;
+    };
+    auto store_x = [&](int chunk) __attribute__((always_inline)) {
+      float pa[8], pb[8], pl[8];
+      if (NRM) {  // this thread's 8 channels are the same for all its rows: (id & 7) == (tid & 7)
+        const float* pt = Ps + (chunk & 1) * 3 * CK + (tid & 7) * 8;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+        for (int k = 0; k < 8; ++k) {
+          pa[k] = pt[k];
+          pb[k] = pt[CK + k];
+          pl[k] = pt[2 * CK + k];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < XREG; ++i) {
         const int id = i * 256 + tid;
         const int r = id >> 3, c8 = (id & 7) * 8;
         if (r < xrows) {
           U16 t;
           const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
           t.u = xreg[i];
-          if (has_nrm) {  // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging
-            const float pa[8] = {nA[0].x, nA[0].y, nA[0].z, nA[0].w, nA[1].x, nA[1].y, nA[1].z, nA[1].w};
-            const float pb[8] = {nB[0].x, nB[0].y, nB[0].z, nB[0].w, nB[1].x, nB[1].y, nB[1].z, nB[1].w};
-            const float pl[8] = {nAl[0].x, nAl[0].y, nAl[0].z, nAl[0].w, nAl[1].x, nAl[1].y, nAl[1].z, nAl[1].w};
+          if (NRM) {  // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               float y = __builtin_fmaf((float)t.h[k], pa[k], pb[k]);
@@ -168,65 +185,68 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
         }
       }
     };
-    auto load_w = [&](int it) {
-      if ((a.dbg & 1) && it > 1) return;  // timing experiment: no W traffic after the prologue
+    // four named registers instead of an array: hipcc kept a `uint4 wreg[4]` captured by the lambdas in scratch memory
+    // (global load -> wait -> scratch store), which turned the prefetch into a synchronous copy
+    uint4 w0, w1, w2, w3;
+    auto load_w = [&](int it) __attribute__((always_inline)) {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
-      const bf16_t* wt = a.w + ((long long)(widx0 + tap * wstep) * a.CoutP + n0) * a.CinP + chunk * CK;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = i * 256 + tid;
-        const int n = id >> 3, c8 = (id & 7) * 8;
-        wreg[i] = *(const uint4*)(wt + (long long)n * a.CinP + c8);
-      }
+      const bf16_t* wt = a.w + ((long long)(widx0 + tap * wstep) * a.CoutP + n0) * a.CinP + chunk * CK + (long long)(tid >> 3) * a.CinP + (tid & 7) * 8;
+      const long long step = (long long)32 * a.CinP;  // 256 threads cover 32 rows of 8 chunks
+      w0 = *(const uint4*)(wt);
+      w1 = *(const uint4*)(wt + step);
+      w2 = *(const uint4*)(wt + 2 * step);
+      w3 = *(const uint4*)(wt + 3 * step);
       asm volatile("" ::: "memory");
     };
-    auto store_w = [&](bf16_t* Ws) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int id = i * 256 + tid;
-        const int n = id >> 3, c8 = (id & 7) * 8;
-        *(uint4*)(Ws + n * XLD + c8) = wreg[i];
-      }
+    auto store_w = [&](bf16_t* Ws) __attribute__((always_inline)) {
+      bf16_t* d = Ws + (tid >> 3) * XLD + (tid & 7) * 8;
+      *(uint4*)(d) = w0;
+      *(uint4*)(d + 32 * XLD) = w1;
+      *(uint4*)(d + 64 * XLD) = w2;
+      *(uint4*)(d + 96 * XLD) = w3;
     };
 
     // ---- prologue
     load_x(0);
     load_w(0);
-    store_x();
+    store_p(0);
     store_w(Ws0);
+    __syncthreads();
+    store_x(0);
     __syncthreads();
     if (nit > 1) load_w(1);
 
-    const int arow = wr * 64 + (lane & 31);       // + mi*32 + tap shift
-    const int brow = wc * 64 + (lane & 31);       // + ni*32
+    const int arow = wr * WM + (lane & 31);  // + mi*32 + tap shift
+    const int brow = wc * 64 + (lane & 31);  // + ni*32
     const int kofs = 8 * (lane >> 5);
 
     for (int it = 0; it < nit; ++it) {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
       const bf16_t* Ws = (it & 1) ? Ws1 : Ws0;
-      // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land
       const bool last_tap = tap == ntaps - 1;
-      if (tap == 0 && chunk + 1 < nchunk && !(a.dbg & 2)) load_x(chunk + 1);
+      // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land
+      if (tap == 0 && chunk + 1 < nchunk) load_x(chunk + 1);
 
       const int shift = (off0 + tap * dstep) - min_off;  // row shift of this tap inside the X slab
       const bf16_t* xa = Xs + (arow + shift) * XLD + kofs;
       const bf16_t* wb = Ws + brow * XLD + kofs;
 #pragma unroll
       for (int ks = 0; ks < CK / 16; ++ks) {
-        const bf16x8 a0 = *(const bf16x8*)(xa + ks * 16);
-        const bf16x8 a1 = *(const bf16x8*)(xa + 32 * XLD + ks * 16);
         const bf16x8 b0 = *(const bf16x8*)(wb + ks * 16);
         const bf16x8 b1 = *(const bf16x8*)(wb + 32 * XLD + ks * 16);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const bf16x8 av = *(const bf16x8*)(xa + mi * 32 * XLD + ks * 16);
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[mi][1], 0, 0, 0);
+        }
       }
       if (it + 1 < nit) {
         store_w((it & 1) ? Ws0 : Ws1);  // buffer last read in iteration it-1; every wave has passed that barrier
+        if (tap == 0 && chunk + 1 < nchunk) store_p(chunk + 1);  // parameter loads were issued with load_x above
         if (last_tap) {
           __syncthreads();  // all waves are done with the X slab
-          store_x();
+          store_x(chunk + 1);
         }
         __syncthreads();
         if (it + 2 < nit) load_w(it + 2);
@@ -235,125 +255,139 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
     __syncthreads();  // main-loop LDS is dead; the epilogue tile aliases it
   }
 
-  // ---- epilogue: accumulators -> fp32 LDS tile -> coalesced rows ----------------------------------------
-  if (tile_live) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = wc * 64 + ni * 32 + (lane & 31);
-        const float bs = a.bias ? a.bias[n0 + col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          float v = acc[mi][ni][r] + bs;
-          if (a.act == KK_ACT_LRELU) v = v > 0.f ? v : v * a.act_slope;
-          else if (a.act == KK_ACT_GELU) v = gelu_exact(v);
-          Cs[row * CLD + col] = v;
-        }
-      }
-    __syncthreads();
-  }
+  // ---- epilogue: per 128 rows, accumulators -> fp32 LDS tile -> coalesced rows --------------------------------------
   TO* ob = (TO*)a.out + (long long)b * a.obs;
   const TO* rb = a.res ? (const TO*)a.res + (long long)b * a.rbs : nullptr;
   const int n = n0 + (tid & 15) * 8;  // this thread's 8 output channels (same for all its rows)
+  const int nc = n < a.Cout ? n : 0;  // clamped for the unconditional loads
   const int lo_hi = a.Lo_rows - 1;
   constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
+  float bias8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bias8[k] = a.bias ? a.bias[n0 + (tid & 15) * 8 + k] : 0.f;  // bias has CoutP entries
   float st_s[8], st_q[8];  // column sums / sums of squares of the values this thread stores
 #pragma unroll
   for (int k = 0; k < 8; ++k) st_s[k] = st_q[k] = 0.f;
+
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    int opv[4];
-    bool wr_ok[4], live[4];
-    uint4 rres[4][VEC], rold[4][VEC];
+  for (int pass = 0; pass < BM / 128; ++pass) {
+    if (tile_live) {
+      if (pass > 0) __syncthreads();  // previous pass's readers are done with Cs
+      // rows [128*pass, 128*pass + 128) of the block tile: WM = 128 -> wave row `pass`; WM = 64 -> both wave rows
+      if (WM == 64 || wr == pass) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = ((half * 4 + i) * 256 + tid) >> 4;
-      const int q = q0 + row;
-      const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
-      opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
-      wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
-      live[i] = tile_live && op < Lout;
-    }
-    const int nc = n < a.Cout ? n : 0;  // clamped channel for the unconditional loads
-    if (rb) {  // wave-uniform
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+          for (int ni = 0; ni < 2; ++ni) {
+            const int col = wc * 64 + ni * 32 + (lane & 31);
+            const int rbase = (WM == 64 ? wr * 64 : 0) + mi * 32 + 4 * (lane >> 5);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
-    }
-    if (a.accumulate) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) rold[i][v] = *((const uint4*)(ob + (long long)opv[i] * a.ldo + nc) + v);
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = ((half * 4 + i) * 256 + tid) >> 4;
-      float v[8];
-      if (tile_live) {
-        const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
-        const float4 c1 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8 + 4);
-        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 0.f;
-      }
-      if (rb) {
-        if (sizeof(TO) == 2) {
-          U16 t;
-          t.u = rres[i][0];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
-        } else {
-          U32x8 t;
-          t.u[0] = rres[i][0];
-          t.u[1] = rres[i][VEC - 1];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += t.f[k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= a.scale;
-      if (a.accumulate) {
-        if (sizeof(TO) == 2) {
-          U16 t;
-          t.u = rold[i][0];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
-        } else {
-          U32x8 t;
-          t.u[0] = rold[i][0];
-          t.u[1] = rold[i][VEC - 1];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += t.f[k];
-        }
-      }
-      if (!live[i]) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 0.f;
-      }
-      if (wr_ok[i]) {
-        TO* dst = ob + (long long)opv[i] * a.ldo + n;
-        if (sizeof(TO) == 2) {
-          U16 t;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
-          *(uint4*)dst = t.u;
-          if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float r = (float)t.h[k];
-              st_s[k] += r;
-              st_q[k] = __builtin_fmaf(r, r, st_q[k]);
-            }
+            for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];
           }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      int opv[4];
+      bool wr_ok[4], live[4];
+      uint4 rres[4][VEC], rold[4][VEC];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = ((half * 4 + i) * 256 + tid) >> 4;
+        const int q = q0 + pass * 128 + row;
+        const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
+        opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
+        wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
+        live[i] = tile_live && op < Lout;
+      }
+      if (rb) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
+      }
+      if (a.accumulate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) rold[i][v] = *((const uint4*)(ob + (long long)opv[i] * a.ldo + nc) + v);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = ((half * 4 + i) * 256 + tid) >> 4;
+        float v[8];
+        if (tile_live) {
+          const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
+          const float4 c1 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8 + 4);
+          v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
         } else {
-          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-          *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+        if (a.act == KK_ACT_LRELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.act_slope;
+        } else if (a.act == KK_ACT_GELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = gelu_exact(v[k]);
+        }
+        if (rb) {
+          if (sizeof(TO) == 2) {
+            U16 t;
+            t.u = rres[i][0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+          } else {
+            U32x8 t;
+            t.u[0] = rres[i][0];
+            t.u[1] = rres[i][VEC - 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= a.scale;
+        if (a.accumulate) {
+          if (sizeof(TO) == 2) {
+            U16 t;
+            t.u = rold[i][0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+          } else {
+            U32x8 t;
+            t.u[0] = rold[i][0];
+            t.u[1] = rold[i][VEC - 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+          }
+        }
+        if (!live[i]) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        if (wr_ok[i]) {
+          TO* dst = ob + (long long)opv[i] * a.ldo + n;
+          if (sizeof(TO) == 2) {
+            U16 t;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
+            *(uint4*)dst = t.u;
+            if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float r = (float)t.h[k];
+                st_s[k] += r;
+                st_q[k] = __builtin_fmaf(r, r, st_q[k]);
+              }
+            }
+          } else {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
         }
       }
     }
@@ -388,6 +422,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(KKMfmaArgs a) {
   }
 }
 
+template <typename TO, int WM, bool NRM>
+int launch_one(const KKMfmaArgs& a, int B, hipStream_t st) {
+  using G = Geo<2 * WM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<TO, WM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_done = true;
+  }
+  const int nphase = a.mode == KK_CONVT ? a.stride : 1;
+  dim3 grid(kk_cdiv(a.Q, 2 * WM), a.CoutP / BN, B * nphase);
+  hipLaunchKernelGGL((conv_mfma_kernel<TO, WM, NRM>), grid, dim3(256), G::LDS_BYTES, st, a);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil) {
@@ -398,6 +447,18 @@ bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil) 
   return halo <= MAX_HALO;
 }
 
+// rows of the output tile a launch with Q rows per phase uses (128 or 256); also the statistics tile size
+int kk_mfma_tile_rows(int Q) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("KK_MFMA_BM");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 128 || forced == 256) return forced;
+  (void)Q;
+  return 128;  // measured (tools/bench_conv.py): the 256-row variant spills 25-70 VGPRs and is 25-35 % slower on every shape
+}
+
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st) {
   if (a.Q <= 0 || B <= 0) return 0;
   if (a.CinP % CK != 0 || a.CoutP % BN != 0) return kk_fail("conv_mfma: CinP must be a multiple of 64 and CoutP of 128");
@@ -405,22 +466,13 @@ int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t s
   if (((uintptr_t)a.x & 15) || ((uintptr_t)a.out & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15))
     return kk_fail("conv_mfma: pointers must be 16-byte aligned");
   if (a.ldx < a.CinP) return kk_fail("conv_mfma: input pitch smaller than the padded channel count");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
+  if (a.nrm_a && (a.nrm_stride % 4 != 0 || a.nrm_stride < a.CinP)) return kk_fail("conv_mfma: bad AdaIN parameter pitch");
+  const bool big = kk_mfma_tile_rows(a.Q) == 256;
+  const bool nrm = a.nrm_a != nullptr;
+  if (out_dtype == KK_BF16) {
+    if (big) return nrm ? launch_one<bf16_t, 128, true>(a, B, st) : launch_one<bf16_t, 128, false>(a, B, st);
+    return nrm ? launch_one<bf16_t, 64, true>(a, B, st) : launch_one<bf16_t, 64, false>(a, B, st);
   }
-  const int nphase = a.mode == KK_CONVT ? a.stride : 1;
-  dim3 grid(kk_cdiv(a.Q, BM), a.CoutP / BN, B * nphase);
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("KK_MFMA_DBG"); dbg = e ? atoi(e) : 0; }
-  KKMfmaArgs a2 = a;
-  a2.dbg = dbg;
-  if (out_dtype == KK_BF16)
-    hipLaunchKernelGGL(conv_mfma_kernel<bf16_t>, grid, dim3(256), LDS_BYTES, st, a2);
-  else
-    hipLaunchKernelGGL(conv_mfma_kernel<float>, grid, dim3(256), LDS_BYTES, st, a2);
-  KK_CHECK_LAUNCH();
-  return 0;
+  if (nrm) return kk_fail("conv_mfma: fused AdaIN input needs a bf16 output");
+  return big ? launch_one<float, 128, false>(a, B, st) : launch_one<float, 64, false>(a, B, st);
 }

@@ -40,6 +40,7 @@ struct KKMfmaArgs {
   int stat_ntiles;
 };
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
+int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
 
 // ---- normalisation family (kk_norm.hip)

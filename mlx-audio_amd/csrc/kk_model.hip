@@ -744,7 +744,7 @@ struct Ctx {
       g.nrm_a = o.nrm_a; g.nrm_b = o.nrm_b; g.nrm_stride = fz_stride; g.nrm_act = o.nrm_act; g.nrm_slope = o.nrm_slope;
       g.nrm_alpha = o.nrm_alpha; g.nrm_C = o.nrm_C;
       if (o.want_stats) {
-        last_ntiles = kk_cdiv(Q, 128) * (o.mode == KK_CONVT ? o.stride : 1);
+        last_ntiles = kk_cdiv(Q, kk_mfma_tile_rows(Q)) * (o.mode == KK_CONVT ? o.stride : 1);
         if ((size_t)B * last_ntiles * 2 * w.Cout > fz_part_floats) return kk_fail("internal: statistics scratch too small");
         g.stat_part = fz_part;
         g.stat_ntiles = last_ntiles;
