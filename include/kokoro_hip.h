@@ -127,6 +127,9 @@ int kk_op_layernorm(void* stream, int B, const void* x, int ldx, const void* res
 /* LSTM recurrence  --  modules.py:152-239 */
 int kk_op_lstm(void* stream, int B, const float* xproj, const float* whT, int H, int L_rows, const int32_t* len, void* out, int ldo,
                int dtype);
+/* the same recurrence for H = 256 with Wh given as bf16 [2][4H][H] (row = gate row, i|f|g|o) and kept on chip */
+int kk_op_lstm_bf16(void* stream, int B, const float* xproj, const void* wh_bf16, int L_rows, const int32_t* len, void* out, int ldo,
+                    int dtype);
 /* AlbertSelfAttention core  --  modules.py:497-512 */
 int kk_op_attention(void* stream, int B, const void* qkv, int ld, int T_rows, const int32_t* len, int heads, void* out, int ldo, int dtype);
 /* SourceModuleHnNSF + MLXSTFT.transform  --  istftnet.py:606-680,463-495 */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "kk_op_adain": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _i]),
     "kk_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _f, _vp, _i, _i]),
     "kk_op_lstm": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "kk_op_lstm_bf16": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i]),
     "kk_op_attention": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
     "kk_op_source_stft": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _vp, _i, _i]),
     "kk_op_istft_head": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i]),

@@ -128,6 +128,8 @@ struct KKLstmArgs {
   KKLen len;
 };
 int kk_launch_lstm(const KKLstmArgs& a, int B, int dtype, hipStream_t st);
+// bf16 mode, H = 256: Wh [2][4H][H] bf16 kept in registers + LDS for the whole sequence
+int kk_launch_lstm_h256_bf16(const KKLstmArgs& a, const void* whb, int B, int dtype, hipStream_t st);
 
 // ---- Albert pieces (kk_albert.hip)
 struct KKEmbedArgs {

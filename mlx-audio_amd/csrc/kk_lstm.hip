@@ -60,3 +60,121 @@ int kk_launch_lstm(const KKLstmArgs& a, int B, int dtype, hipStream_t st) {
   KK_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode, H = 256: Wh stays ON CHIP for the whole sequence.  Thread g owns gate row g (256 weights, bf16):
+// the first 192 live in 96 VGPRs (packed pairs), the last 64 in a 144-byte-pitched LDS row (conflict-free b128 reads).
+// h is kept in LDS as 128 packed bf16 pairs that every lane reads as broadcasts; one v_dot2c_f32_bf16 per weight pair.
+// Per step: 128 dot2 + 32 broadcast reads + 8 row reads per lane, two barriers -- no L2 weight traffic at all (the
+// generic kernel above re-streams 1 MiB of fp32 Wh per step and direction).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot2(unsigned w, unsigned h, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, h), acc, false);
+}
+
+constexpr int LH = 256, LG = 1024, KR = 192, KL = 64, LWLD = 72;  // LDS row pitch in bf16 elements (144 B)
+constexpr int LSTM_LDS = LG * LWLD * 2 + 128 * 4 + LG * 4;
+
+// 512 threads, each owning TWO gate rows (t and t + 512): 2 x 96 weight registers fit the 256-VGPR budget of two waves
+// per SIMD without spilling, and every broadcast read of h feeds two dot products.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_h256_bf16_kernel(KKLstmArgs a, const bf16_t* whb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  bf16_t* wl = (bf16_t*)lsm;                              // [1024][72]
+  unsigned* hb = (unsigned*)(lsm + LG * LWLD * 2);        // [128] packed (h[2k], h[2k+1])
+  float* g_s = (float*)(lsm + LG * LWLD * 2 + 128 * 4);   // [1024]
+  const int b = blockIdx.x, dir = blockIdx.y, t0 = threadIdx.x;
+  const int g0 = t0, g1 = t0 + 512;
+  const int L = kk_len(a.len, b);
+  const bf16_t* wrow0 = whb + ((long long)dir * LG + g0) * LH;
+  const bf16_t* wrow1 = whb + ((long long)dir * LG + g1) * LH;
+  unsigned wa[KR / 2], wb[KR / 2];
+#pragma unroll
+  for (int q = 0; q < KR / 8; ++q) {
+    const uint4 v = *(const uint4*)(wrow0 + q * 8);
+    wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
+    const uint4 u = *(const uint4*)(wrow1 + q * 8);
+    wb[4 * q] = u.x; wb[4 * q + 1] = u.y; wb[4 * q + 2] = u.z; wb[4 * q + 3] = u.w;
+  }
+#pragma unroll
+  for (int q = 0; q < KL / 8; ++q) {
+    *(uint4*)(wl + g0 * LWLD + q * 8) = *(const uint4*)(wrow0 + KR + q * 8);
+    *(uint4*)(wl + g1 * LWLD + q * 8) = *(const uint4*)(wrow1 + KR + q * 8);
+  }
+  if (t0 < 128) hb[t0] = 0u;
+  const float* xp = a.xproj + (long long)b * a.Lmax * 2 * LG + (long long)dir * LG;
+  T* ob = (T*)a.out + (long long)b * a.obs + dir * LH;
+  float c = 0.f;
+  const bool tanh1 = t0 < 256;  // row t0 + 512 is a `g` (tanh) row for t0 < 256, an `o` (sigmoid) row otherwise
+  const long long tfirst = dir ? L - 1 : 0;
+  float xn0 = L > 0 ? xp[tfirst * 2 * LG + g0] : 0.f, xn1 = L > 0 ? xp[tfirst * 2 * LG + g1] : 0.f;
+  __syncthreads();
+  for (int step = 0; step < L; ++step) {
+    const int t = dir ? (L - 1 - step) : step;
+    float acc0 = xn0, acc1 = xn1;
+    if (step + 1 < L) {  // prefetch the next step's input projection
+      const long long tn = dir ? t - 1 : t + 1;
+      xn0 = xp[tn * 2 * LG + g0];
+      xn1 = xp[tn * 2 * LG + g1];
+    }
+#pragma unroll
+    for (int q = 0; q < KR / 8; ++q) {
+      const uint4 hv = *(const uint4*)(hb + 4 * q);
+      acc0 = dot2(wa[4 * q], hv.x, acc0);     acc1 = dot2(wb[4 * q], hv.x, acc1);
+      acc0 = dot2(wa[4 * q + 1], hv.y, acc0); acc1 = dot2(wb[4 * q + 1], hv.y, acc1);
+      acc0 = dot2(wa[4 * q + 2], hv.z, acc0); acc1 = dot2(wb[4 * q + 2], hv.z, acc1);
+      acc0 = dot2(wa[4 * q + 3], hv.w, acc0); acc1 = dot2(wb[4 * q + 3], hv.w, acc1);
+    }
+#pragma unroll
+    for (int q = 0; q < KL / 8; ++q) {
+      const uint4 hv = *(const uint4*)(hb + KR / 2 + 4 * q);
+      const uint4 w0 = *(const uint4*)(wl + g0 * LWLD + q * 8);
+      const uint4 w1 = *(const uint4*)(wl + g1 * LWLD + q * 8);
+      acc0 = dot2(w0.x, hv.x, acc0); acc1 = dot2(w1.x, hv.x, acc1);
+      acc0 = dot2(w0.y, hv.y, acc0); acc1 = dot2(w1.y, hv.y, acc1);
+      acc0 = dot2(w0.z, hv.z, acc0); acc1 = dot2(w1.z, hv.z, acc1);
+      acc0 = dot2(w0.w, hv.w, acc0); acc1 = dot2(w1.w, hv.w, acc1);
+    }
+    g_s[g0] = sigmoidf_(acc0);                           // rows 0..511 are i / f
+    g_s[g1] = tanh1 ? tanhf(acc1) : sigmoidf_(acc1);     // rows 512..767 g, 768..1023 o
+    __syncthreads();
+    if (t0 < LH) {  // waves 0..3: whole waves, so the shuffle below is safe
+      const float ig = g_s[t0], fg = g_s[LH + t0], gg = g_s[2 * LH + t0], og = g_s[3 * LH + t0];
+      c = fg * c + ig * gg;
+      const float h = og * tanhf(c);
+      kk_st(ob + (long long)t * a.ldo + t0, h);
+      const float hn = __shfl_down(h, 1);
+      if ((t0 & 1) == 0) {
+        const bf16x2_t p = {(bf16_t)h, (bf16_t)hn};
+        hb[t0 >> 1] = __builtin_bit_cast(unsigned, p);
+      }
+    }
+    __syncthreads();
+  }
+  if (t0 < LH)
+    for (int t = L; t < a.Lmax; ++t) kk_st(ob + (long long)t * a.ldo + t0, 0.f);
+}
+
+}  // namespace
+
+int kk_launch_lstm_h256_bf16(const KKLstmArgs& a, const void* whb, int B, int dtype, hipStream_t st) {
+  if (B <= 0 || a.Lmax <= 0) return 0;
+  if (a.H != LH) return kk_fail("lstm_h256_bf16: H must be 256");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
+    (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
+    attr_done = true;
+  }
+  dim3 grid(B, 2);
+  if (dtype == KK_F32)
+    hipLaunchKernelGGL(lstm_h256_bf16_kernel<float>, grid, dim3(512), LSTM_LDS, st, a, (const bf16_t*)whb);
+  else
+    hipLaunchKernelGGL(lstm_h256_bf16_kernel<bf16_t>, grid, dim3(512), LSTM_LDS, st, a, (const bf16_t*)whb);
+  KK_CHECK_LAUNCH();
+  return 0;
+}

@@ -55,7 +55,7 @@ struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
   // bf16 MFMA pack [Kw][CoutP][CinP] (bf16 mode, eligible layers only); bias is then padded to CoutP
   bool mfma = false;
   size_t wb_off = 0;
-  int CinP = 0, CoutP = 0;
+  int CinP = 0, CoutP = 0, Cout8 = 0;
   const bf16_t* wb = nullptr;
 };
 struct VecW {
@@ -67,6 +67,10 @@ struct LstmW {
   ConvW in;  // [1][I][8H], bias = b_ih + b_hh, columns dir*4H + gate row
   VecW whT;  // [2][H][4H]
   int H = 0;
+  // bf16 mode, H = 256: Wh as bf16 [2][4H][H] for the on-chip recurrence kernel
+  bool has_whb = false;
+  size_t whb_off = 0;
+  const void* whb = nullptr;
 };
 struct AdainRef {
   size_t off = 0;  // offset of gamma in the style vector of its half; beta at off + C
@@ -320,8 +324,10 @@ struct Packer {
   }
   // bf16 MFMA pack of wsrc[o][k][i] -> [k][CoutP][CinP] (two bf16 per float slot of the staging vector)
   void pack_mfma(ConvW& c, const std::vector<float>& wsrc, int O, int K, int I) {
-    if (m->adt != KK_BF16 || O % 8 != 0 || O < 64 || I < 32) return;
+    // Cout is rounded up to 8 for the kernel (zero weights / bias): only used when the destination has room (Ctx::can_mfma)
+    if (m->adt != KK_BF16 || O < 16 || I < 16) return;
     c.mfma = true;
+    c.Cout8 = kk_cdiv(O, 8) * 8;
     c.CinP = kk_cdiv(I, 64) * 64;
     c.CoutP = kk_cdiv(O, 128) * 128;
     const size_t nel = (size_t)K * c.CoutP * c.CinP;
@@ -403,6 +409,14 @@ struct Packer {
     }
     l.in = pack_oki(w, 2 * G, 1, I, &b);
     l.whT = put(whT);
+    if (m->adt == KK_BF16 && H == 256) {
+      l.has_whb = true;
+      l.whb_off = alloc(((size_t)2 * G * H + 1) / 2);
+      uint16_t* dst = (uint16_t*)&m->pack[l.whb_off];
+      for (int d = 0; d < 2; ++d)
+        for (int g = 0; g < G; ++g)
+          for (int j = 0; j < H; ++j) dst[((size_t)d * G + g) * H + j] = f32_to_bf16_rne(whT[((size_t)d * H + j) * G + g]);
+    }
     return l;
   }
 };
@@ -481,7 +495,11 @@ void resolve(kk_model* m, ConvW& c) {
   c.wb = c.mfma ? (const bf16_t*)(m->dev + c.wb_off) : nullptr;
 }
 void resolve(kk_model* m, VecW& v) { v.p = v.n ? m->dev + v.off : nullptr; }
-void resolve(kk_model* m, LstmW& l) { resolve(m, l.in); resolve(m, l.whT); }
+void resolve(kk_model* m, LstmW& l) {
+  resolve(m, l.in);
+  resolve(m, l.whT);
+  l.whb = l.has_whb ? (const void*)(m->dev + l.whb_off) : nullptr;
+}
 void resolve(kk_model* m, ResBlk1d& r) {
   resolve(m, r.conv1); resolve(m, r.conv2);
   if (r.learned) resolve(m, r.sc);
@@ -666,6 +684,7 @@ struct ConvOpt {
   const float* nrm_alpha = nullptr;
   int nrm_C = 0;
   bool want_stats = false;
+  bool pad_out_ok = false;  // the destination may receive up to 7 extra zero channels (Cout rounded up to 8)
 };
 
 struct Ctx {
@@ -752,7 +771,7 @@ struct Ctx {
       g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
       g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
       if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
-      g.Cout = w.Cout; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
+      g.Cout = w.Cout8; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
       g.Q = Q; g.Lo_rows = out.rows; g.lin = lin; g.lout = lout; g.in_slope = o.in_slope; g.scale = o.scale; g.accumulate = o.accumulate;
       g.act = o.act; g.act_slope = o.act_slope;
       prof_start();
@@ -769,8 +788,10 @@ struct Ctx {
 
   bool can_mfma(const ConvW& w, const Buf& x, const Buf& out, const ConvOpt& o) const {
     const bool al16 = !(((uintptr_t)x.p | (uintptr_t)out.p | (uintptr_t)(o.res ? o.res->p : nullptr)) & 15);
-    return w.mfma && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
-           kk_mfma_eligible(w.Cin, w.Cout, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
+    // a Cout that is not a multiple of 8 is rounded up: legal only for a whole-buffer destination with spare pitch, no residual
+    const bool cout_ok = w.Cout == w.Cout8 || (out.ld >= w.Cout8 && !o.res && !o.accumulate && o.pad_out_ok);
+    return w.mfma && cout_ok && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
+           kk_mfma_eligible(w.Cin, w.Cout8, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
            (!o.res || o.res->ld % 8 == 0) && al16 && !m->force_generic;
   }
 
@@ -864,7 +885,8 @@ struct Ctx {
     memset(&a, 0, sizeof a);
     a.xproj = xproj; a.whT = l.whT.p; a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.H = l.H; a.Lmax = Lmax; a.len = len;
     prof_start();
-    const int rc = kk_launch_lstm(a, B, out.dtype, st);
+    const int rc = (l.whb && adt == KK_BF16 && !m->force_generic) ? kk_launch_lstm_h256_bf16(a, l.whb, B, out.dtype, st)
+                                                                    : kk_launch_lstm(a, B, out.dtype, st);
     prof_stop(4, 2.0 * B * Lmax * 2 * 4 * l.H * l.H, 2.0 * Lmax * 4 * l.H * l.H * 4.0 * B);
     return rc;
   }
@@ -1202,7 +1224,8 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   // ---- Generator front end (istftnet.py:770-775)
   float* phase = c.f32((size_t)B * 9 * L2);
   float* har_source = c.f32((size_t)B * Nw);
-  Buf har = c.act(Tf, 24);
+  Buf har = c.act(Tf, c.adt == KK_BF16 ? 64 : 24);  // bf16: pitch 64 so the k=1 noise conv can run on the MFMA kernel
+  if (!c.dry && c.adt == KK_BF16 && hipMemsetAsync(har.p, 0, (size_t)B * har.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
   if (!c.dry) {
     KKSourceArgs sa;
     memset(&sa, 0, sizeof sa);
@@ -1269,6 +1292,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   ConvOpt op;
   op.pad = 3;
   op.in_slope = 0.01f;
+  op.pad_out_ok = true;  // cp has pitch 24 for 22 channels
   KK_TRY(c.conv(m->conv_post, cur, lTf, cp, lTf, Tf, op));
   KK_TRY(c.dbg("conv_post", cp, 22));
   if (!c.dry) {
@@ -1423,6 +1447,15 @@ extern "C" int kk_op_lstm(void* stream, int B, const float* xproj, const float* 
   a.xproj = xproj; a.whT = whT; a.out = out; a.obs = (long long)L_rows * ldo; a.ldo = ldo; a.H = H; a.Lmax = L_rows;
   a.len = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
   return kk_launch_lstm(a, B, dtype, (hipStream_t)stream);
+}
+
+extern "C" int kk_op_lstm_bf16(void* stream, int B, const float* xproj, const void* wh_bf16, int L_rows, const int32_t* len, void* out,
+                               int ldo, int dtype) {
+  KKLstmArgs a;
+  memset(&a, 0, sizeof a);
+  a.xproj = xproj; a.out = out; a.obs = (long long)L_rows * ldo; a.ldo = ldo; a.H = 256; a.Lmax = L_rows;
+  a.len = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
+  return kk_launch_lstm_h256_bf16(a, wh_bf16, B, dtype, (hipStream_t)stream);
 }
 
 extern "C" int kk_op_attention(void* stream, int B, const void* qkv, int ld, int T_rows, const int32_t* len, int heads, void* out, int ldo,

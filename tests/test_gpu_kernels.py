@@ -492,3 +492,40 @@ def test_conv1x1_mfma_upsampled_input(lib):
     ref = np.einsum("blc,oc->blo", np.repeat(x, 2, axis=1), w[:, 0, :])
     got = run_conv_bf16(lib, x, w, None, in_shift=1, Lout=2 * L, out_f32=True)
     assert err_stats(got, ref)["rel_max"] < 2e-5
+
+
+def test_lstm_h256_bf16_on_chip(lib):
+    """The on-chip-weights recurrence (bf16 Wh, bf16-rounded h into the dot products, fp32 state) against the oracle run
+    on the same bf16-rounded weights: differences come from rounding h to bf16 inside the recurrent product only."""
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(77)
+    H, I, L, B = 256, 640, 60, 3
+    lens = [60, 17, 1]
+    s = 1.0 / math.sqrt(H)
+    w = {}
+    for d in ("forward", "backward"):
+        w[f"l.Wx_{d}"] = rng.uniform(-s, s, (4 * H, I)).astype(np.float32)
+        w[f"l.Wh_{d}"] = _bf(rng.uniform(-s, s, (4 * H, H)).astype(np.float32))
+        w[f"l.bias_ih_{d}"] = rng.uniform(-s, s, 4 * H).astype(np.float32)
+        w[f"l.bias_hh_{d}"] = rng.uniform(-s, s, 4 * H).astype(np.float32)
+    orc = _oracle_stub(w)
+    x = rng.standard_normal((B, L, I)).astype(np.float32)
+    xproj = np.zeros((B, L, 2, 4 * H), np.float32)
+    whb = np.zeros((2, 4 * H, H), np.float32)
+    for di, d in enumerate(("forward", "backward")):
+        xproj[:, :, di] = (w[f"l.bias_ih_{d}"] + w[f"l.bias_hh_{d}"]) + x @ w[f"l.Wx_{d}"].T
+        whb[di] = w[f"l.Wh_{d}"]
+    out = torch.full((B, L, 2 * H), 3.0, device="cuda")
+    xp, wt = dev(xproj), dev(whb, torch.bfloat16)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_lstm_bf16(stream(), B, P(xp), P(wt), L, P(lend), P(out), 2 * H, _lib.KK_F32)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for b, n in enumerate(lens):
+        ref = orc.lstm(torch.tensor(x[b : b + 1, :n]), "l").numpy()[0]
+        e = err_stats(got[b, :n], ref)
+        report(f"lstm_bf16/b{b}", **e)
+        assert e["max_abs"] < 2e-2 and e["rms_rel"] < 1e-2  # h is rounded to bf16 (2^-9) before each recurrent product
+        assert np.all(got[b, n:] == 0)
