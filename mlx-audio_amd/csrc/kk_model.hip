@@ -1271,12 +1271,12 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
       ou.res = &xsrc;
       KK_TRY(c.conv(m->ups[i], cur, lcur, xi, lst, Qt, ou));
     } else {
-      // zero left pad of one frame (istftnet.py:786-787, "ReflectionPad1d" = mx.pad) then + x_source:
-      // copy x_source, then accumulate the transposed conv one row further down.
+      // zero left pad of one frame (istftnet.py:786-787, "ReflectionPad1d" = mx.pad) then + x_source: the transposed conv
+      // writes one row further down with x_source (same offset) as its residual; row 0 is x_source[0] alone.
       if (!c.dry)
-        KK_TRY(kk_launch_copy_slice(xsrc.p, xsrc.bs, xsrc.ld, xi.p, xi.bs, xi.ld, 0, Cst, Lst, lst, B, xi.dtype, c.st));
-      ou.accumulate = 1;
-      Buf xi1 = xi.row_offset(1);
+        KK_TRY(kk_launch_copy_slice(xsrc.p, xsrc.bs, xsrc.ld, xi.p, xi.bs, xi.ld, 0, Cst, 1, KKLen{lenF, 1, 0}, B, xi.dtype, c.st));
+      Buf xi1 = xi.row_offset(1), xs1 = xsrc.row_offset(1);
+      ou.res = &xs1;
       KK_TRY(c.conv(m->ups[i], cur, lcur, xi1, lTfm1, Qt, ou));
     }
     KK_TRY(c.dbg(i == 0 ? "gen_pre_res0" : "gen_pre_res1", xi, Cst));

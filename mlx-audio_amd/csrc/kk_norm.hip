@@ -93,6 +93,95 @@ __global__ __launch_bounds__(256) void stats_final_kernel(KKStatsArgs a) {
   }
 }
 
+// fused partials (un-shifted per-tile column sums from the conv epilogues) -> mean / rstd / folded AdaIN parameters.
+// Deterministic: fixed lane -> tile assignment and a fixed reduction tree.
+__global__ __launch_bounds__(1024) void norm_finalize_tiles_kernel(KKStatsArgs a) {
+  __shared__ double red[2][32][33];
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
+  const int L = kk_len(a.len, b);
+  double S = 0.0, SS = 0.0;
+  if (c < a.C && L > 0) {
+    const float* pb = a.partial + (long long)b * a.nchunk * 2 * a.C;
+    for (int k = tl; k < a.nchunk; k += 32) {
+      S += (double)pb[(long long)k * 2 * a.C + c];
+      SS += (double)pb[(long long)k * 2 * a.C + a.C + c];
+    }
+  }
+  red[0][tl][cl] = S;
+  red[1][tl][cl] = SS;
+  __syncthreads();
+  if (tl != 0) return;
+  if (c >= a.C) {
+    if (a.pa && c < a.Cp) {
+      a.pa[(long long)b * a.pstride + c] = 0.f;
+      a.pb[(long long)b * a.pstride + c] = 0.f;
+    }
+    return;
+  }
+  for (int k = 1; k < 32; ++k) {
+    S += red[0][k][cl];
+    SS += red[1][k][cl];
+  }
+  float mean = 0.f, rstd = 0.f;
+  if (L > 0) {
+    const double m = S / L;
+    double var = SS / L - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  if (a.mean) a.mean[(long long)b * a.C + c] = mean;
+  if (a.rstd) a.rstd[(long long)b * a.C + c] = rstd;
+  if (a.pa) {
+    const float g = 1.0f + a.gb[(long long)b * a.gbs + c], be = a.gb[(long long)b * a.gbs + a.C + c];
+    const float A = rstd * g;
+    a.pa[(long long)b * a.pstride + c] = A;
+    a.pb[(long long)b * a.pstride + c] = be - mean * A;
+  }
+}
+
+// 16-byte vectorised statistics pass for bf16 tensors with C in {64, 128, 256, 512, 1024}: a thread owns 8 channels,
+// C/8 threads cover a row, 256/(C/8) rows advance together.  Same partial layout as stats_partial_kernel.
+__global__ __launch_bounds__(256) void stats_partial_bf16v_kernel(KKStatsArgs a) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int L = kk_len(a.len, b);
+  const int r0 = chunk * a.rows_per_chunk;
+  const int r1 = min(L, r0 + a.rows_per_chunk);
+  const int cwt = a.C >> 3, RL = 256 / cwt;  // threads per row, rows in flight
+  const int cl = tid % cwt, rl = tid / cwt;
+  const bf16_t* xb = (const bf16_t*)a.x + (long long)b * a.xbs;
+  union { uint4 u; bf16_t h[8]; } t;
+  float sh[8], s[8], q[8];
+  t.u = *(const uint4*)(xb + cl * 8);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sh[k] = (float)t.h[k]; s[k] = 0.f; q[k] = 0.f; }
+  if (L > 0) {
+    for (int r = r0 + rl; r < r1; r += RL) {
+      t.u = *(const uint4*)(xb + (long long)r * a.ldx + cl * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = (float)t.h[k] - sh[k];
+        s[k] += v;
+        q[k] = __builtin_fmaf(v, v, q[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][tid][k] = s[k]; red[1][tid][k] = q[k]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < RL; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s[k] += red[0][j * cwt + cl][k]; q[k] += red[1][j * cwt + cl][k]; }
+    float* pb = a.partial + ((long long)b * a.nchunk + chunk) * 2 * a.C + cl * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pb[k] = s[k]; pb[a.C + k] = q[k]; }
+  }
+}
+
 // ---------------------------------------------------------------- AdaIN apply (+ act, + pool)
 __device__ __forceinline__ float act_apply(float y, int act, float slope, float alpha, bool fast) {
   if (act == KK_ACT_LRELU) return y > 0.f ? y : y * slope;
@@ -236,7 +325,11 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
     hipLaunchKernelGGL(stats_partial_kernel<float>, g1, dim3(256), 0, st, a, cw);
     hipLaunchKernelGGL(stats_final_kernel<float>, g2, dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, a, cw);
+    const bool vec = (a.C == 64 || a.C == 128 || a.C == 256 || a.C == 512 || a.C == 1024) && a.ldx % 8 == 0 && !((uintptr_t)a.x & 15);
+    if (vec)
+      hipLaunchKernelGGL(stats_partial_bf16v_kernel, g1, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, a, cw);
     hipLaunchKernelGGL(stats_final_kernel<bf16_t>, g2, dim3(256), 0, st, a);
   }
   KK_CHECK_LAUNCH();
@@ -245,9 +338,14 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
 
 int kk_launch_norm_finalize(KKStatsArgs a, int B, hipStream_t st) {
   if (B <= 0 || a.C <= 0) return 0;
-  if (a.fused != 2) a.fused = 1;
   const int cover = a.pa ? (a.Cp > a.C ? a.Cp : a.C) : a.C;
-  hipLaunchKernelGGL(stats_final_kernel<float>, dim3(kk_cdiv(cover, 256), B), dim3(256), 0, st, a);
+  if (a.fused != 2) {
+    a.fused = 1;
+    // hundreds of per-tile partials per channel: 32 channels x 32 tile lanes per workgroup, then an LDS tree
+    hipLaunchKernelGGL(norm_finalize_tiles_kernel, dim3(kk_cdiv(cover, 32), B), dim3(1024), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(stats_final_kernel<float>, dim3(kk_cdiv(cover, 256), B), dim3(256), 0, st, a);
+  }
   KK_CHECK_LAUNCH();
   return 0;
 }
