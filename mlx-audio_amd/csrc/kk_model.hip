@@ -833,14 +833,15 @@ struct Ctx {
   float* st_partial = nullptr;
   float* st_mean = nullptr;
   float* st_rstd = nullptr;
-  static constexpr int ROWS_PER_CHUNK = 512;
+  // rows one workgroup of the stand-alone statistics pass walks: short tensors (decoder, F rows) need more workgroups
+  static int rows_per_chunk(int Lmax) { return Lmax >= 8192 ? 512 : 64; }
 
   int stats(const Buf& x, int C, int Lmax, KKLen len) {
     if (dry) return 0;
     KKStatsArgs a;
     memset(&a, 0, sizeof a);
     a.x = x.p; a.xbs = x.bs; a.ldx = x.ld; a.C = C; a.Lmax = Lmax; a.len = len;
-    a.partial = st_partial; a.rows_per_chunk = ROWS_PER_CHUNK; a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
+    a.partial = st_partial; a.rows_per_chunk = rows_per_chunk(Lmax); a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
     prof_start();
     const int rc = kk_launch_instnorm_stats(a, B, x.dtype, st);
     prof_stop(2, 3.0 * B * Lmax * C, (double)B * Lmax * C * esz(x.dtype));
@@ -1154,7 +1155,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     // upper bounds: partial = B * chunks(L) * 2 * C for every (L, C) pair used below
     size_t pmax = 0, cmax = 0;
     auto upd = [&](int L, int C) {
-      pmax = std::max(pmax, kk_stats_partial_floats(B, C, L, Ctx::ROWS_PER_CHUNK));
+      pmax = std::max(pmax, kk_stats_partial_floats(B, C, L, Ctx::rows_per_chunk(L)));
       cmax = std::max(cmax, (size_t)B * C);
     };
     upd(Fmax, H); upd(L2, H); upd(L2, H / 2); upd(Fmax, H + 2); upd(Fmax, DH + 2 + 64); upd(Fmax, DH); upd(L2, DH + 2 + 64);

@@ -189,21 +189,50 @@ __global__ __launch_bounds__(256) void stft20_kernel(const float* hs, int Nmax, 
 }
 
 // ------------------------------------------------------------------ iSTFT head
+// HBM-bound by design: 22 inputs and 5 fp32 outputs per frame column (64 B with bf16 input).
+//   phase 0  the workgroup's [259 frames][ldx] input tile is ONE contiguous span: coalesced 16-byte loads into LDS
+//   phase 1  one thread per frame: exp / sin / sincos, then the 20-point inverse real DFT using the o <-> 20-o symmetry
+//            (cos terms even, sin terms odd: 11 x 18 FMAs instead of 20 x 18), x periodic Hann -> LDS
+//   phase 2  one thread per hop block: <= 4 overlapping frames added in ascending frame order (the reference's
+//            scatter-add order, utils.py:138-147), divided by the window sum accumulated in the same order
+//   phase 3  the 1280 output samples of the workgroup leave as coalesced 8-byte stores
 constexpr int IH_FR = 256;  // hop-blocks per workgroup
+constexpr int IH_NF = IH_FR + 3;
 
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
                                                          long long wbs, Tables tb) {
-  __shared__ float ys[IH_FR + 3][21];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ism[];
+  float* ys = (float*)ism;                          // [259][21]
+  unsigned char* tile = ism + IH_NF * 21 * 4;       // [259][ldx] input tile, later the output staging
   const int b = blockIdx.y, tid = threadIdx.x;
   const int Tf = len_frames ? len_frames[b] : Tfmax;
   const int g0 = blockIdx.x * IH_FR;  // first hop-block of this workgroup
+  const int f0 = g0 - 3;              // first frame of the tile
   const T* xb = x + (long long)b * xbs;
-  // phase 1: windowed inverse real DFT of frames g0-3 .. g0+IH_FR-1
-  for (int i = tid; i < IH_FR + 3; i += 256) {
-    const int f = g0 - 3 + i;
+  const int row_bytes = ldx * (int)sizeof(T);
+  // ---- phase 0: coalesced tile load (frames clamped into [0, Tfmax): out-of-range frames are masked in phase 1)
+  {
+    const int fa = f0 < 0 ? 0 : f0;
+    const int fb = min(f0 + IH_NF, Tfmax);
+    const long long bytes = (long long)(fb - fa) * row_bytes;
+    const unsigned char* src = (const unsigned char*)(xb + (long long)fa * ldx);
+    unsigned char* dst = tile + (long long)(fa - f0) * row_bytes;
+    if (bytes > 0) {
+      if ((((uintptr_t)src) & 15) == 0 && (row_bytes & 15) == 0) {
+        for (long long o = (long long)tid * 16; o < bytes; o += 256 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+      } else {
+        for (long long o = (long long)tid * sizeof(T); o < bytes; o += 256 * sizeof(T)) *(T*)(dst + o) = *(const T*)(src + o);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: windowed inverse real DFT of frames f0 .. f0+258
+  for (int i = tid; i < IH_NF; i += 256) {
+    const int f = f0 + i;
+    float* yo = ys + i * 21;
     if (f >= 0 && f < Tf) {
-      const T* xr = xb + (long long)f * ldx;
+      const T* xr = (const T*)(tile + (long long)i * row_bytes);
       float re[11], im[11];
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
@@ -215,46 +244,62 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
         re[k] = mag * c;
         im[k] = mag * s;
       }
+      // x[o] = (re0 + (-1)^o re10 + 2 (C[o] - S[o])) / 20,  x[20-o] = (.. + 2 (C[o] + S[o])) / 20
 #pragma unroll
-      for (int o = 0; o < 20; ++o) {
-        float acc = 0.f;
+      for (int o = 0; o <= 10; ++o) {
+        float C = 0.f, S = 0.f;
 #pragma unroll
         for (int k = 1; k < 10; ++k) {
           const int m = (k * o) % 20;
-          acc = __builtin_fmaf(re[k], tb.cs[m], acc);
-          acc = __builtin_fmaf(-im[k], tb.sn[m], acc);
+          C = __builtin_fmaf(re[k], tb.cs[m], C);
+          S = __builtin_fmaf(im[k], tb.sn[m], S);
         }
-        const float v = (re[0] + ((o & 1) ? -re[10] : re[10]) + 2.0f * acc) * 0.05f;
-        ys[i][o] = v * tb.hann_per[o];
+        const float dc = re[0] + ((o & 1) ? -re[10] : re[10]);
+        yo[o] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[o];
+        if (o > 0 && o < 10) yo[20 - o] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - o];
       }
     } else {
 #pragma unroll
-      for (int o = 0; o < 20; ++o) ys[i][o] = 0.f;
+      for (int o = 0; o < 20; ++o) yo[o] = 0.f;
     }
   }
   __syncthreads();
-  // phase 2: overlap-add in ascending frame order, normalise by the window sum, trim 10 | 10
+  // ---- phase 2: overlap-add in ascending frame order, normalise by the window sum, trim 10 | 10
+  float* stage = (float*)tile;  // [256][5]
   const int g = g0 + tid;
   const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
-  float* wb = wav + (long long)b * wbs;
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
     const int n = 5 * g + r - 10;
-    if (n < 0 || n >= 5 * (Tfmax - 1)) continue;
     float v = 0.f;
-    if (n < nout) {
+    if (n >= 0 && n < nout) {
       float acc = 0.f, ws = 0.f;
 #pragma unroll
       for (int j = 3; j >= 0; --j) {
         const int f = g - j;
         if (f >= 0 && f < Tf) {
-          acc += ys[tid + 3 - j][5 * j + r];
+          acc += ys[(tid + 3 - j) * 21 + 5 * j + r];
           ws += tb.hann_per[5 * j + r];
         }
       }
       v = ws != 0.f ? acc / ws : acc;
     }
-    wb[n] = v;
+    stage[tid * 5 + r] = v;
+  }
+  __syncthreads();
+  // ---- phase 3: samples n0 .. n0+1279 (n0 = 5*g0 - 10, even) as float2 stores
+  float* wb = wav + (long long)b * wbs;
+  const long long n0 = 5LL * g0 - 10;
+  const long long ntot = 5LL * (Tfmax - 1);
+  for (int e = tid; e < IH_FR * 5 / 2; e += 256) {
+    const long long n = n0 + 2 * e;
+    const float2 v = *(const float2*)(stage + 2 * e);
+    if (n >= 0 && n + 1 < ntot && ((((uintptr_t)(wb + n)) & 7) == 0)) {
+      *(float2*)(wb + n) = v;
+    } else {
+      if (n >= 0 && n < ntot) wb[n] = v.x;
+      if (n + 1 >= 0 && n + 1 < ntot) wb[n + 1] = v.y;
+    }
   }
 }
 
@@ -289,17 +334,22 @@ int kk_launch_stft20(const float* har_source, int Nmax, const int* lenN, void* h
 int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav, long long wbs, int B,
                          int dtype, int fast, hipStream_t st) {
   if (B <= 0 || Tfmax <= 0) return 0;
+  if (ldx < 22 || ldx > 64) return kk_fail("istft_head: input pitch must be in [22, 64]");
   dim3 grid(kk_cdiv(Tfmax + 3, IH_FR), B);
+  const size_t esz = dtype == KK_F32 ? 4 : 2;
+  size_t tile = (size_t)IH_NF * ldx * esz;
+  if (tile < (size_t)IH_FR * 5 * 4) tile = (size_t)IH_FR * 5 * 4;
+  const size_t lds = (size_t)IH_NF * 21 * 4 + ((tile + 15) & ~(size_t)15);
   if (dtype == KK_F32) {
     if (fast)
-      hipLaunchKernelGGL((istft_head_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
     else
-      hipLaunchKernelGGL((istft_head_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
   } else {
     if (fast)
-      hipLaunchKernelGGL((istft_head_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
     else
-      hipLaunchKernelGGL((istft_head_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
   }
   KK_CHECK_LAUNCH();
   return 0;
