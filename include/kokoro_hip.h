@@ -116,6 +116,13 @@ int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, int Lin_rows,
                       const float* bias, int Cout, int Kw, int transposed, int stride, int pad, int dil, int in_shift, float in_slope,
                       int act, float act_slope, const void* res, int ldr, float scale, int accumulate, void* out, int ldo, int Lout_rows,
                       const int32_t* lout, int out_dtype);
+/* the fused resblock form of the bf16 path: y = act(x * nrm_a[b][c] + nrm_b[b][c]) applied while the input is staged
+ * (AdaIN1d + Snake / LeakyReLU, istftnet.py:333-337,382) and per-tile column sums / sums of squares of the stored output
+ * (stat_part [B][ntiles][2][Cout], the next InstanceNorm's statistics, istftnet.py:229-230) */
+int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, const void* w_bf16, int CinP,
+                            int CoutP, const float* bias, int Cin, int Cout, int Kw, int pad, int dil, const float* nrm_a,
+                            const float* nrm_b, int nrm_stride, int nrm_act, float nrm_slope, const float* nrm_alpha, const void* res,
+                            int ldr, float scale, void* out, int ldo, float* stat_part, int* stat_ntiles_out);
 /* InstanceNorm statistics + AdaIN1d + activation (+ pool)  --  istftnet.py:216-268,327-338,382,874-882 */
 int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta, int gbs,
                 int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out, int ldo, int Cpad,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "kk_abi_version": (_i, []),
     "kk_op_conv1d": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _f, _i, _vp, _i, _i, _vp, _i, _i]),
     "kk_op_conv1d_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _vp, _i, _f, _i, _vp, _i, _i, _vp, _i]),
+    "kk_op_conv1d_bf16_fused": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _f,
+                                     _vp, _i, _vp, C.POINTER(C.c_int)]),
     "kk_op_adain": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _i]),
     "kk_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _f, _vp, _i, _i]),
     "kk_op_lstm": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),

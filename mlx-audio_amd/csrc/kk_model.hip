@@ -1412,6 +1412,28 @@ extern "C" int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, in
   return kk_launch_conv_mfma(g, B, out_dtype, (hipStream_t)stream);
 }
 
+// the fused form used inside the bf16 generator: AdaIN + activation applied to the input while it is staged
+// (y = act(x * nrm_a[b][c] + nrm_b[b][c])), per-tile column sums of the stored output written to stat_part
+extern "C" int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, const void* w_bf16, int CinP,
+                                       int CoutP, const float* bias, int Cin, int Cout, int Kw, int pad, int dil, const float* nrm_a,
+                                       const float* nrm_b, int nrm_stride, int nrm_act, float nrm_slope, const float* nrm_alpha,
+                                       const void* res, int ldr, float scale, void* out, int ldo, float* stat_part, int* stat_ntiles_out) {
+  KKMfmaArgs g;
+  memset(&g, 0, sizeof g);
+  g.x = (const bf16_t*)x; g.xbs = (long long)L_rows * ldx; g.ldx = ldx; g.w = (const bf16_t*)w_bf16; g.CinP = CinP; g.CoutP = CoutP; g.bias = bias;
+  g.out = out; g.obs = (long long)L_rows * ldo; g.ldo = ldo; g.res = res; g.rbs = (long long)L_rows * ldr; g.ldr = ldr;
+  g.Cout = Cout; g.Kw = Kw; g.mode = KK_CONV; g.stride = 1; g.pad = pad; g.dil = dil; g.Q = L_rows; g.Lo_rows = L_rows;
+  g.lin = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};
+  g.lout = g.lin;
+  g.in_slope = 1.f; g.scale = scale;
+  g.nrm_a = nrm_a; g.nrm_b = nrm_b; g.nrm_stride = nrm_stride; g.nrm_act = nrm_act; g.nrm_slope = nrm_slope; g.nrm_alpha = nrm_alpha; g.nrm_C = Cin;
+  g.stat_part = stat_part;
+  g.stat_ntiles = kk_cdiv(L_rows, kk_mfma_tile_rows(L_rows));
+  if (stat_ntiles_out) *stat_ntiles_out = g.stat_ntiles;
+  if (!kk_mfma_eligible(CinP, Cout, Kw, KK_CONV, 1, dil)) return kk_fail("kk_op_conv1d_bf16_fused: shape not eligible for the MFMA kernel");
+  return kk_launch_conv_mfma(g, B, KK_BF16, (hipStream_t)stream);
+}
+
 extern "C" int kk_op_adain(void* stream, int B, const void* x, int ldx, int L_rows, const int32_t* len, int C, const float* gamma_beta,
                            int gbs, int act, float slope, const float* alpha, int pool, const float* pool_w, const float* pool_b, void* out,
                            int ldo, int Cpad, int Lout_rows, float* scratch, size_t scratch_floats, int dtype, int fast) {

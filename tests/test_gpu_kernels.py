@@ -529,3 +529,51 @@ def test_lstm_h256_bf16_on_chip(lib):
         report(f"lstm_bf16/b{b}", **e)
         assert e["max_abs"] < 2e-2 and e["rms_rel"] < 1e-2  # h is rounded to bf16 (2^-9) before each recurrent product
         assert np.all(got[b, n:] == 0)
+
+
+def test_conv_mfma_fused_adain_snake_and_stats(lib):
+    """Fused form of the bf16 generator: AdaIN + Snake while staging the input, column statistics of the output.
+    Reference: the same math in fp32 on the bf16-rounded operands."""
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(91)
+    B, L, Cn, K, d = 2, 700, 128, 7, 3
+    lens = [700, 301]
+    x = _bf(rng.standard_normal((B, L, Cn)).astype(np.float32) * 2 + 0.5)
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    w = _bf((rng.standard_normal((Cn, K, Cn)) / math.sqrt(K * Cn)).astype(np.float32))
+    bias = rng.standard_normal(Cn).astype(np.float32)
+    res = _bf(rng.standard_normal((B, L, Cn)).astype(np.float32))
+    A = (rng.standard_normal((B, Cn)) * 0.5 + 1).astype(np.float32)
+    Bv = (rng.standard_normal((B, Cn)) * 0.3).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    wp, CinP, CoutP = pack_w_bf16(w)
+    bp = np.zeros(CoutP, np.float32)
+    bp[:Cn] = bias
+    xd, wd, bd, rd = dev(x, torch.bfloat16), wp.cuda().contiguous(), dev(bp), dev(res, torch.bfloat16)
+    ad, bvd, ald = dev(A), dev(Bv), dev(alpha)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    out = torch.full((B, L, Cn), 7.0, device="cuda", dtype=torch.bfloat16)
+    ntmax = (L + 127) // 128
+    part = torch.zeros((B, ntmax, 2, Cn), device="cuda")
+    nt = C.c_int(0)
+    rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
+                                     _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    pt = part.cpu().numpy()[:, : nt.value]
+    for b, n in enumerate(lens):
+        y = x[b, :n] * A[b][None, :] + Bv[b][None, :]
+        y = y + (1.0 / alpha)[None, :] * np.sin(alpha[None, :] * y) ** 2
+        y = _bf(y.astype(np.float32))
+        base = F.conv1d(torch.tensor(y)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 9, d).transpose(1, 2)[0]
+        ref = (base + torch.tensor(res[b, :n])).numpy()
+        e = err_stats(got[b, :n], ref)
+        report(f"conv_mfma_fused/out/b{b}", **e)
+        assert e["rel_max"] < 1.5e-2  # bf16 rounding of the transformed input (hardware sin) and of the output
+        assert np.all(got[b, n:] == 0)
+        s1, s2 = pt[b, :, 0].sum(0), pt[b, :, 1].sum(0)
+        np.testing.assert_allclose(s1, got[b, :n].sum(0), rtol=1e-3, atol=2e-2)
+        np.testing.assert_allclose(s2, (got[b, :n].astype(np.float64) ** 2).sum(0), rtol=1e-3)

@@ -30,7 +30,7 @@ SHAPES = [
 ]
 
 
-def run(name, B, L, Cin, Cout, K, dil, res, iters=5):
+def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
     CinP, CoutP = (Cin + 63) // 64 * 64, (Cout + 127) // 128 * 128
     x = (torch.randn(B, L, CinP, device="cuda") * 1.0).to(torch.bfloat16)
     w = (torch.randn(K, CoutP, CinP, device="cuda") / (K * Cin) ** 0.5).to(torch.bfloat16)
@@ -39,11 +39,23 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5):
     r = torch.randn(B, L, Cout, device="cuda").to(torch.bfloat16) if res else None
     pad = (K * dil - dil) // 2
 
-    def call():
+    A = torch.rand(B, CinP, device="cuda") + 0.5
+    Bv = torch.randn(B, CinP, device="cuda") * 0.2
+    al = torch.rand(Cin, device="cuda") + 0.5
+    part = torch.zeros(B * ((L + 127) // 128) * 2 * Cout, device="cuda")
+    nt = C.c_int(0)
+
+    def call_fused():
+        rc = lib.kk_op_conv1d_bf16_fused(st(), B, P(x), CinP, L, None, P(w), CinP, CoutP, P(bias), Cin, Cout, K, pad, dil, P(A), P(Bv), CinP,
+                                         3, 0.0, P(al), P(r), Cout, 1.0, P(out), Cout, P(part), C.byref(nt))
+        assert rc == 0, lib.kk_last_error()
+
+    def call_plain():
         rc = lib.kk_op_conv1d_bf16(st(), B, P(x), CinP, L, None, P(w), CinP, CoutP, P(bias), Cout, K, 0, 1, pad, dil, 0, 1.0, 0, 0.0, P(r), Cout,
                                    1.0, 0, P(out), Cout, L, None, _lib.KK_BF16)
         assert rc == 0, lib.kk_last_error()
 
+    call = call_fused if fused else call_plain
     call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,12 +67,16 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5):
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * L * Cin * Cout * K
     by = B * L * (Cin + Cout * (2 if res else 1)) * 2
-    return {"name": name, "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+    return {"name": name + ("+fused" if fused else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
 
 
 if __name__ == "__main__":
-    sel = sys.argv[1:] or None
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    fused = "--fused" in sys.argv
+    sel = args or None
     for s in SHAPES:
         if sel and s[0] not in sel:
             continue
-        print(json.dumps(run(*s)), flush=True)
+        if fused and (s[3] != s[4] or not s[7]):
+            continue
+        print(json.dumps(run(*s, fused=fused)), flush=True)
