@@ -154,6 +154,7 @@ int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channel
 int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
 int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
 void kk_debug_clear(kk_model* m);
+void kk_debug_set_mfma3(int on); /* process-wide: route long bf16 convs to the experimental persistent 256-row kernel */
 void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----

@@ -58,8 +58,9 @@ constexpr int HD = 64, KT = 64;
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(KKAttnArgs a) {
-  __shared__ float Ks[KT][HD + 1];
-  __shared__ float Vs[KT][HD + 1];
+  // every lane reads the SAME key row (broadcast), so no padding is needed and rows can be read as float4
+  __shared__ __attribute__((aligned(16))) float Ks[KT][HD];
+  __shared__ __attribute__((aligned(16))) float Vs[KT][HD];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, h = blockIdx.x;
   const int L = kk_len(a.len, b);
@@ -89,13 +90,25 @@ __global__ __launch_bounds__(256) void attention_kernel(KKAttnArgs a) {
       for (int kr = 0; kr < kn; ++kr) {
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s = __builtin_fmaf(q[d], Ks[kr][d], s);
+        for (int d = 0; d < HD; d += 4) {
+          const float4 k4 = *(const float4*)&Ks[kr][d];
+          s = __builtin_fmaf(q[d], k4.x, s);
+          s = __builtin_fmaf(q[d + 1], k4.y, s);
+          s = __builtin_fmaf(q[d + 2], k4.z, s);
+          s = __builtin_fmaf(q[d + 3], k4.w, s);
+        }
         const float mn = fmaxf(m, s);
         const float corr = expf(m - mn);
         const float p = expf(s - mn);
         l = l * corr + p;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = __builtin_fmaf(p, Vs[kr][d], o[d] * corr);
+        for (int d = 0; d < HD; d += 4) {
+          const float4 v4 = *(const float4*)&Vs[kr][d];
+          o[d] = __builtin_fmaf(p, v4.x, o[d] * corr);
+          o[d + 1] = __builtin_fmaf(p, v4.y, o[d + 1] * corr);
+          o[d + 2] = __builtin_fmaf(p, v4.z, o[d + 2] * corr);
+          o[d + 3] = __builtin_fmaf(p, v4.w, o[d + 3] * corr);
+        }
         m = mn;
       }
     }

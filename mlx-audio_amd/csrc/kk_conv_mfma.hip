@@ -459,6 +459,8 @@ int kk_mfma_tile_rows(int Q) {
   return 128;  // measured (tools/bench_conv.py): the 256-row variant spills 25-70 VGPRs and is 25-35 % slower on every shape
 }
 
+int kk_mfma_stat_tile_rows(const KKMfmaArgs& a, int out_dtype) { return kk_mfma3_usable(a, out_dtype) ? 256 : kk_mfma_tile_rows(a.Q); }
+
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st) {
   if (a.Q <= 0 || B <= 0) return 0;
   if (a.CinP % CK != 0 || a.CoutP % BN != 0) return kk_fail("conv_mfma: CinP must be a multiple of 64 and CoutP of 128");
@@ -467,6 +469,7 @@ int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t s
     return kk_fail("conv_mfma: pointers must be 16-byte aligned");
   if (a.ldx < a.CinP) return kk_fail("conv_mfma: input pitch smaller than the padded channel count");
   if (a.nrm_a && (a.nrm_stride % 4 != 0 || a.nrm_stride < a.CinP)) return kk_fail("conv_mfma: bad AdaIN parameter pitch");
+  if (kk_mfma3_usable(a, out_dtype)) return kk_launch_conv_mfma3(a, B, st);  // long sequences: persistent 256-row kernel
   const bool big = kk_mfma_tile_rows(a.Q) == 256;
   const bool nrm = a.nrm_a != nullptr;
   if (out_dtype == KK_BF16) {

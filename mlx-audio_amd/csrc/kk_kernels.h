@@ -42,6 +42,12 @@ struct KKMfmaArgs {
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
+// persistent 256-row variant for long sequences (kk_conv_mfma3.hip); kk_launch_conv_mfma dispatches to it
+bool kk_mfma3_usable(const KKMfmaArgs& a, int out_dtype);
+void kk_set_mfma3(int on);
+int kk_launch_conv_mfma3(const KKMfmaArgs& a, int B, hipStream_t st);
+// rows per statistics tile of the kernel kk_launch_conv_mfma will pick for these arguments
+int kk_mfma_stat_tile_rows(const KKMfmaArgs& a, int out_dtype);
 
 // ---- normalisation family (kk_norm.hip)
 struct KKStatsArgs {

@@ -763,17 +763,11 @@ struct Ctx {
       g.nrm_a = o.nrm_a; g.nrm_b = o.nrm_b; g.nrm_stride = fz_stride; g.nrm_act = o.nrm_act; g.nrm_slope = o.nrm_slope;
       g.nrm_alpha = o.nrm_alpha; g.nrm_C = o.nrm_C;
       if (o.want_stats) {
-        last_ntiles = kk_cdiv(Q, kk_mfma_tile_rows(Q)) * (o.mode == KK_CONVT ? o.stride : 1);
+        last_ntiles = kk_cdiv(Q, kk_mfma_stat_tile_rows(g, out.dtype)) * (o.mode == KK_CONVT ? o.stride : 1);
         if ((size_t)B * last_ntiles * 2 * w.Cout > fz_part_floats) return kk_fail("internal: statistics scratch too small");
         g.stat_part = fz_part;
         g.stat_ntiles = last_ntiles;
       }
-      g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
-      g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
-      if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
-      g.Cout = w.Cout8; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
-      g.Q = Q; g.Lo_rows = out.rows; g.lin = lin; g.lout = lout; g.in_slope = o.in_slope; g.scale = o.scale; g.accumulate = o.accumulate;
-      g.act = o.act; g.act_slope = o.act_slope;
       prof_start();
       const int rc = kk_launch_conv_mfma(g, B, out.dtype, st);
       prof_stop(1, flops, bytes);
@@ -1428,7 +1422,7 @@ extern "C" int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int l
   g.in_slope = 1.f; g.scale = scale;
   g.nrm_a = nrm_a; g.nrm_b = nrm_b; g.nrm_stride = nrm_stride; g.nrm_act = nrm_act; g.nrm_slope = nrm_slope; g.nrm_alpha = nrm_alpha; g.nrm_C = Cin;
   g.stat_part = stat_part;
-  g.stat_ntiles = kk_cdiv(L_rows, kk_mfma_tile_rows(L_rows));
+  g.stat_ntiles = kk_cdiv(L_rows, kk_mfma_stat_tile_rows(g, KK_BF16));
   if (stat_ntiles_out) *stat_ntiles_out = g.stat_ntiles;
   if (!kk_mfma_eligible(CinP, Cout, Kw, KK_CONV, 1, dil)) return kk_fail("kk_op_conv1d_bf16_fused: shape not eligible for the MFMA kernel");
   return kk_launch_conv_mfma(g, B, KK_BF16, (hipStream_t)stream);
@@ -1537,6 +1531,7 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
   m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
 }
+extern "C" void kk_debug_set_mfma3(int on) { kk_set_mfma3(on); }
 extern "C" void kk_debug_clear(kk_model* m) {
   if (!m) return;
   m->dbg_over.clear();

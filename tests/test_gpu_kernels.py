@@ -563,7 +563,7 @@ def test_conv_mfma_fused_adain_snake_and_stats(lib):
     assert rc == 0, lib.kk_last_error()
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
-    pt = part.cpu().numpy()[:, : nt.value]
+    pt = part.cpu().numpy().reshape(-1)[: B * nt.value * 2 * Cn].reshape(B, nt.value, 2, Cn)
     for b, n in enumerate(lens):
         y = x[b, :n] * A[b][None, :] + Bv[b][None, :]
         y = y + (1.0 / alpha)[None, :] * np.sin(alpha[None, :] * y) ** 2
@@ -577,3 +577,100 @@ def test_conv_mfma_fused_adain_snake_and_stats(lib):
         s1, s2 = pt[b, :, 0].sum(0), pt[b, :, 1].sum(0)
         np.testing.assert_allclose(s1, got[b, :n].sum(0), rtol=1e-3, atol=2e-2)
         np.testing.assert_allclose(s2, (got[b, :n].astype(np.float64) ** 2).sum(0), rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent 256-row MFMA kernel (long sequences, Q >= 2048)
+# ------------------------------------------------------------------------------------------------
+LONG_CASES = [
+    ("long_k3", 128, 128, 3, 1, 1, 2500),
+    ("long_k11_d5", 128, 128, 11, 25, 5, 2300),
+    ("long_k7_c256", 256, 256, 7, 3, 1, 2100),
+]
+
+
+@pytest.fixture
+def mfma3(lib):
+    lib.kk_debug_set_mfma3(1)
+    yield
+    lib.kk_debug_set_mfma3(0)
+
+
+@pytest.mark.parametrize("case", LONG_CASES, ids=[c[0] for c in LONG_CASES])
+def test_conv_mfma3_long(lib, mfma3, case):
+    name, Cin, Cout, K, p, d, L = case
+    rng = np.random.default_rng(hash(name) % 2**31)
+    B = 3
+    lens = [L, L - 777, 130]
+    x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+    w = _bf((rng.standard_normal((Cout, K, Cin)) / math.sqrt(K * Cin)).astype(np.float32))
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = _bf(rng.standard_normal((B, L, Cout)).astype(np.float32))
+    init = _bf(rng.standard_normal((B, L, Cout)).astype(np.float32))
+    got = run_conv_bf16(lib, x, w, bias, pad=p, dil=d, in_slope=0.1, res=res, scale=1 / 3, accumulate=True, out_init=init, Lout=L, lin=lens,
+                        lout=lens)
+    for b, n in enumerate(lens):
+        xin = np.where(x[b, :n] > 0, x[b, :n], _bf(x[b, :n] * 0.1))
+        base = F.conv1d(torch.tensor(xin)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, p, d).transpose(1, 2)[0]
+        ref = ((base + torch.tensor(res[b, :n])) * (1 / 3) + torch.tensor(init[b, :n])).numpy()
+        e = err_stats(got[b, :n], ref)
+        report(f"conv_mfma3/{name}/b{b}", **e)
+        assert e["rel_max"] < 6e-3
+        assert np.all(got[b, n:] == 0)
+
+
+def test_conv_mfma3_transposed_and_fused(lib, mfma3):
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(123)
+    # transposed conv (ups.1 geometry) on the persistent kernel: Q = L >= 2048 rows per phase
+    K, s, p, Cin, Cout, L, B = 12, 6, 3, 256, 128, 2200, 2
+    x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+    w_iko = _bf((rng.standard_normal((Cin, K, Cout)) / math.sqrt(K * Cin / s)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = F.conv_transpose1d(torch.tensor(x).transpose(1, 2), torch.tensor(w_iko).permute(0, 2, 1), torch.tensor(b), s, p).transpose(1, 2).numpy()
+    got = run_conv_bf16(lib, x, np.transpose(w_iko, (2, 1, 0)), b, transposed=True, stride=s, pad=p, Lout=ref.shape[1])
+    e = err_stats(got, ref)
+    report("conv_mfma3/convT_k12s6", **e)
+    assert e["rel_max"] < 6e-3
+    # fused AdaIN + Snake input and output statistics
+    L, Cn, K, d = 2600, 128, 7, 3
+    lens = [2600, 2049]
+    x = _bf(rng.standard_normal((B, L, Cn)).astype(np.float32) * 2 + 0.5)
+    for bb, n in enumerate(lens):
+        x[bb, n:] = 0
+    w = _bf((rng.standard_normal((Cn, K, Cn)) / math.sqrt(K * Cn)).astype(np.float32))
+    bias = rng.standard_normal(Cn).astype(np.float32)
+    res = _bf(rng.standard_normal((B, L, Cn)).astype(np.float32))
+    A = (rng.standard_normal((B, Cn)) * 0.5 + 1).astype(np.float32)
+    Bv = (rng.standard_normal((B, Cn)) * 0.3).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    wp, CinP, CoutP = pack_w_bf16(w)
+    bp = np.zeros(CoutP, np.float32)
+    bp[:Cn] = bias
+    xd, wd, bd, rd = dev(x, torch.bfloat16), wp.cuda().contiguous(), dev(bp), dev(res, torch.bfloat16)
+    ad, bvd, ald = dev(A), dev(Bv), dev(alpha)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    out = torch.full((B, L, Cn), 7.0, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros((B, (L + 127) // 128, 2, Cn), device="cuda")
+    nt = C.c_int(0)
+    rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
+                                     _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    pt = part.cpu().numpy().reshape(-1)[: B * nt.value * 2 * Cn].reshape(B, nt.value, 2, Cn)  # pitch = the kernel's tile count
+    for bb, n in enumerate(lens):
+        y = x[bb, :n] * A[bb][None, :] + Bv[bb][None, :]
+        y = y + (1.0 / alpha)[None, :] * np.sin(alpha[None, :] * y) ** 2
+        y = _bf(y.astype(np.float32))
+        base = F.conv1d(torch.tensor(y)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 9, d).transpose(1, 2)[0]
+        ref = (base + torch.tensor(res[bb, :n])).numpy()
+        e = err_stats(got[bb, :n], ref)
+        report(f"conv_mfma3/fused/b{bb}", **e)
+        assert e["rel_max"] < 1.5e-2
+        assert np.all(got[bb, n:] == 0)
+        np.testing.assert_allclose(pt[bb, :, 0].sum(0), got[bb, :n].sum(0), rtol=1e-3, atol=5e-2)
+        np.testing.assert_allclose(pt[bb, :, 1].sum(0), (got[bb, :n].astype(np.float64) ** 2).sum(0), rtol=1e-3)
