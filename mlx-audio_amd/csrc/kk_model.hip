@@ -762,6 +762,12 @@ struct Ctx {
       memset(&g, 0, sizeof g);
       g.nrm_a = o.nrm_a; g.nrm_b = o.nrm_b; g.nrm_stride = fz_stride; g.nrm_act = o.nrm_act; g.nrm_slope = o.nrm_slope;
       g.nrm_alpha = o.nrm_alpha; g.nrm_C = o.nrm_C;
+      g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
+      g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
+      if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
+      g.Cout = w.Cout8; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
+      g.Q = Q; g.Lo_rows = out.rows; g.lin = lin; g.lout = lout; g.in_slope = o.in_slope; g.scale = o.scale; g.accumulate = o.accumulate;
+      g.act = o.act; g.act_slope = o.act_slope;
       if (o.want_stats) {
         last_ntiles = kk_cdiv(Q, kk_mfma_stat_tile_rows(g, out.dtype)) * (o.mode == KK_CONVT ? o.stride : 1);
         if ((size_t)B * last_ntiles * 2 * w.Cout > fz_part_floats) return kk_fail("internal: statistics scratch too small");
