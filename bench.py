@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B=1 p50 latency measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +130,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_end() if not args.no_profile else None
+
+    # p50 per-utterance latency (second half of BASELINE.json's metric): B = 1, same shapes, after the timed region
+    p50_ms = None
+    if rank == 0 and not args.no_latency:
+        i1, l1, T1 = eng.pack_ids(utts[:1])
+        r1, s1, f1 = ref_s[:1].contiguous(), speed[:1].contiguous(), forced[:1].contiguous()
+        w1 = torch.empty((1, 600 * Fmax), dtype=torch.float32, device=dev)
+        lat = []
+        for i in range(12):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.forward(i1, l1, r1, s1, Fmax, forced_dur=f1, noise_mode=_lib.NOISE_PHILOX, seed=7 + i, out=w1)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        p50_ms = float(np.median(lat[2:]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,19 +170,34 @@ def main():
                    "global_batch": Bglob, "parallelism": f"utterance-shard x{world}"},
     }
     if rank == 0:
+        if p50_ms is not None:
+            out["p50_latency_ms_b1"] = p50_ms
+            out["p50_latency_note"] = "one 128-phoneme utterance (16.25 s audio), kk_forward + sync, median of 10 after 2 warm-ups"
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(args.dtype)
+        except Exception:
+            pmc = None
         if prof is not None:
             # dominant kernel = the convolution family (carries ~99 % of the algorithmic FLOPs)
             conv = prof["conv_mfma"] if prof["conv_mfma"]["ms"] > prof["conv_generic"]["ms"] else prof["conv_generic"]
             peak = PEAK_TFLOPS["bf16" if conv is prof["conv_mfma"] else "f32"]
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            traffic = None
+            if pmc and conv is prof["conv_mfma"] and "conv_mfma" in pmc:
+                c = pmc["conv_mfma"]  # separate --pmc passes, see profiles/r01_pmc_traffic.json (read side reported raw)
+                traffic = (c["fetch_raw_bytes_per_step"] + c["write_bytes_per_step"]) / c["launches_per_step"]
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma" if conv is prof["conv_mfma"] else "conv_generic (fp32 VALU implicit GEMM)",
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "launches_per_step": conv["launches"] / args.steps, "ms_per_step": conv["ms"] / args.steps}
             ih = prof["istft_head"]
             if ih["ms"] > 0:
                 gbs = ih["bytes"] / (ih["ms"] * 1e-3) / 1e9
+                tr = None
+                if pmc and "istft_head" in pmc:
+                    tr = pmc["istft_head"]["fetch_corrected_bytes_per_launch"] + pmc["istft_head"]["write_bytes_per_launch"]
                 out["roofline_istft_head"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                              "traffic": None, "us_per_launch": ih["ms"] / ih["launches"] * 1e3}
+                                              "traffic": tr, "us_per_launch": ih["ms"] / ih["launches"] * 1e3}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
             out["kernel_ms_per_step"]["_sum_bracketed"] = round(tot / args.steps, 3)
