@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default=os.environ.get("KK_BENCH_DTYPE", "float32"), choices=["float32", "bfloat16"])
+    ap.add_argument("--dtype", default=os.environ.get("KK_BENCH_DTYPE", "bfloat16"), choices=["float32", "bfloat16"])
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
