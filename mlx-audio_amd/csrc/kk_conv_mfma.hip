@@ -26,6 +26,7 @@
 #include "kk_kernels.h"
 
 namespace {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,7 +43,8 @@ struct Geo {
   static constexpr int XROWS = BM + MAX_HALO;
   static constexpr int XS_BYTES = XROWS * XLD * 2;
   static constexpr int MAIN_BYTES = XS_BYTES + 2 * WS_BYTES + PS_BYTES;
-  static constexpr int EPI_BYTES = 128 * CLD * 4;
+  static constexpr int RPP = BM == 128 ? 128 : BM / 2;  // rows per epilogue pass (one wave row group for the tall tiles)
+  static constexpr int EPI_BYTES = RPP * CLD * 4;
   static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static constexpr int XREG = (XROWS * 8 + 255) / 256;  // 16-byte chunks of the slab per thread
 };
@@ -58,7 +60,8 @@ union U32x8 {
   float f[8];
 };
 
-template <typename TO, int WM, bool NRM>
+// NRM: 0 = raw input, 1 = AdaIN + Snake while staging, 2 = AdaIN + LeakyReLU(nrm_slope; 1 = identity) while staging
+template <typename TO, int WM, int NRM>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma_kernel(KKMfmaArgs a) {
   constexpr int BM = 2 * WM, MI = WM / 32;
   using G = Geo<BM>;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int which = tid >> 4, c = chunk * CK + (tid & 15) * 4;
         if (which == 0) preg = *(const float4*)(a.nrm_a + (long long)b * a.nrm_stride + c);
         else if (which == 1) preg = *(const float4*)(a.nrm_b + (long long)b * a.nrm_stride + c);
-        else if (a.nrm_act == KK_ACT_SNAKE) {
+        else if (NRM == 1) {
           preg.x = (c + 0) < a.nrm_C ? a.nrm_alpha[c + 0] : 1.0f;
           preg.y = (c + 1) < a.nrm_C ? a.nrm_alpha[c + 1] : 1.0f;
           preg.z = (c + 2) < a.nrm_C ? a.nrm_alpha[c + 2] : 1.0f;
@@ -142,14 +145,44 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (NRM && tid < 48) *(float4*)(Ps + (chunk & 1) * 3 * CK + (tid >> 4) * CK + (tid & 15) * 4) = preg;
     };
     auto store_x = [&](int chunk) __attribute__((always_inline)) {
-      float pa[8], pb[8], pl[8];
-      if (NRM) {  // this thread's 8 channels are the same for all its rows: (id & 7) == (tid & 7)
+      if (NRM) {
+        // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging.  This thread's 8
+        // channels are the same for all its rows ((id & 7) == (tid & 7)); they are handled one packed PAIR at a time so that
+        // only 8 parameter registers are live, and the loop body is branch-free (the activation is a template parameter) so
+        // the transcendental latency of neighbouring elements overlaps.
         const float* pt = Ps + (chunk & 1) * 3 * CK + (tid & 7) * 8;
+        const float slope = a.nrm_slope;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          pa[k] = pt[k];
-          pb[k] = pt[CK + k];
-          pl[k] = pt[2 * CK + k];
+        for (int kk = 0; kk < 4; ++kk) {
+          const float a0 = pt[2 * kk], a1 = pt[2 * kk + 1], b0 = pt[CK + 2 * kk], b1 = pt[CK + 2 * kk + 1];
+          float l0 = 0.f, l1 = 0.f, i0 = 0.f, i1 = 0.f;
+          if (NRM == 1) {  // snake: y + sin^2(alpha y) / alpha; v_sin_f32 takes revolutions
+            const float al0 = pt[2 * CK + 2 * kk], al1 = pt[2 * CK + 2 * kk + 1];
+            l0 = al0 * 0.15915494309189535f;
+            l1 = al1 * 0.15915494309189535f;
+            i0 = __builtin_amdgcn_rcpf(al0);
+            i1 = __builtin_amdgcn_rcpf(al1);
+          }
+#pragma unroll
+          for (int i = 0; i < XREG; ++i) {
+            const unsigned wd = kk == 0 ? xreg[i].x : kk == 1 ? xreg[i].y : kk == 2 ? xreg[i].z : xreg[i].w;
+            float y0 = __builtin_fmaf(__uint_as_float(wd << 16), a0, b0);
+            float y1 = __builtin_fmaf(__uint_as_float(wd & 0xFFFF0000u), a1, b1);
+            if (NRM == 1) {
+              const float s0 = __builtin_amdgcn_sinf(l0 * y0), s1 = __builtin_amdgcn_sinf(l1 * y1);
+              y0 = __builtin_fmaf(i0 * s0, s0, y0);
+              y1 = __builtin_fmaf(i1 * s1, s1, y1);
+            } else {
+              y0 = y0 > 0.f ? y0 : y0 * slope;
+              y1 = y1 > 0.f ? y1 : y1 * slope;
+            }
+            const bf16x2 pk = {(bf16_t)y0, (bf16_t)y1};
+            const unsigned o = __builtin_bit_cast(unsigned, pk);
+            if (kk == 0) xreg[i].x = o;
+            else if (kk == 1) xreg[i].y = o;
+            else if (kk == 2) xreg[i].z = o;
+            else xreg[i].w = o;
+          }
         }
       }
 #pragma unroll
@@ -160,19 +193,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           U16 t;
           const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
           t.u = xreg[i];
-          if (NRM) {  // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              float y = __builtin_fmaf((float)t.h[k], pa[k], pb[k]);
-              if (a.nrm_act == KK_ACT_SNAKE) {
-                const float sn = __sinf(pl[k] * y);
-                y = y + __builtin_amdgcn_rcpf(pl[k]) * (sn * sn);
-              } else if (a.nrm_act == KK_ACT_LRELU) {
-                y = y > 0.f ? y : y * a.nrm_slope;
-              }
-              t.h[k] = (bf16_t)y;
-            }
-          }
           t.u = make_uint4(t.u.x & msk, t.u.y & msk, t.u.z & msk, t.u.w & msk);  // padding rows stay exactly zero
           if (a.in_slope != 1.0f) {
 #pragma unroll
@@ -269,11 +289,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
   for (int k = 0; k < 8; ++k) st_s[k] = st_q[k] = 0.f;
 
+  constexpr int RPP = G::RPP, NPASS = BM / RPP, TASKS = RPP * 16 / 256, TG = TASKS / 2;  // 8 or 6 row tasks per thread and pass
 #pragma unroll
-  for (int pass = 0; pass < BM / 128; ++pass) {
+  for (int pass = 0; pass < NPASS; ++pass) {
     if (tile_live) {
       if (pass > 0) __syncthreads();  // previous pass's readers are done with Cs
-      // rows [128*pass, 128*pass + 128) of the block tile: WM = 128 -> wave row `pass`; WM = 64 -> both wave rows
+      // rows [RPP*pass, RPP*pass + RPP) of the block tile: tall tiles -> wave row `pass`; 128-row tile -> both wave rows
       if (WM == 64 || wr == pass) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -289,13 +310,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      int opv[4];
-      bool wr_ok[4], live[4];
-      uint4 rres[4][VEC], rold[4][VEC];
+      int opv[TG];
+      bool wr_ok[TG], live[TG];
+      uint4 rres[TG][VEC], rold[TG][VEC];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = ((half * 4 + i) * 256 + tid) >> 4;
-        const int q = q0 + pass * 128 + row;
+      for (int i = 0; i < TG; ++i) {
+        const int row = ((half * TG + i) * 256 + tid) >> 4;
+        const int q = q0 + pass * RPP + row;
         const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
         opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
         wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
@@ -303,20 +324,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
       if (rb) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TG; ++i)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
       }
       if (a.accumulate) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TG; ++i)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) rold[i][v] = *((const uint4*)(ob + (long long)opv[i] * a.ldo + nc) + v);
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = ((half * 4 + i) * 256 + tid) >> 4;
+      for (int i = 0; i < TG; ++i) {
+        const int row = ((half * TG + i) * 256 + tid) >> 4;
         float v[8];
         if (tile_live) {
           const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
@@ -422,7 +443,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
-template <typename TO, int WM, bool NRM>
+template <typename TO, int WM, int NRM>
 int launch_one(const KKMfmaArgs& a, int B, hipStream_t st) {
   using G = Geo<2 * WM>;
   static bool attr_done = false;
@@ -447,16 +468,18 @@ bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil) 
   return halo <= MAX_HALO;
 }
 
-// rows of the output tile a launch with Q rows per phase uses (128 or 256); also the statistics tile size
+// rows of the output tile a launch with Q rows per phase uses (128 or 192); also the statistics tile size
 int kk_mfma_tile_rows(int Q) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("KK_MFMA_BM");
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 128 || forced == 256) return forced;
+  if (forced == 128 || forced == 192) return forced;
   (void)Q;
-  return 128;  // measured (tools/bench_conv.py): the 256-row variant spills 25-70 VGPRs and is 25-35 % slower on every shape
+  // measured (tools/bench_conv.py): 192 rows (3 MFMA row blocks per wave, 250 VGPRs, 73 KB LDS -> still two workgroups per CU)
+  // streams a third less W per MFMA than 128 and is 8-10 % faster on every shape; a 256-row variant spilled and was slower
+  return 192;
 }
 
 int kk_mfma_stat_tile_rows(const KKMfmaArgs& a, int out_dtype) { return kk_mfma3_usable(a, out_dtype) ? 256 : kk_mfma_tile_rows(a.Q); }
@@ -470,12 +493,20 @@ int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t s
   if (a.ldx < a.CinP) return kk_fail("conv_mfma: input pitch smaller than the padded channel count");
   if (a.nrm_a && (a.nrm_stride % 4 != 0 || a.nrm_stride < a.CinP)) return kk_fail("conv_mfma: bad AdaIN parameter pitch");
   if (kk_mfma3_usable(a, out_dtype)) return kk_launch_conv_mfma3(a, B, st);  // long sequences: persistent 256-row kernel
-  const bool big = kk_mfma_tile_rows(a.Q) == 256;
-  const bool nrm = a.nrm_a != nullptr;
-  if (out_dtype == KK_BF16) {
-    if (big) return nrm ? launch_one<bf16_t, 128, true>(a, B, st) : launch_one<bf16_t, 128, false>(a, B, st);
-    return nrm ? launch_one<bf16_t, 64, true>(a, B, st) : launch_one<bf16_t, 64, false>(a, B, st);
+  const int rows = kk_mfma_tile_rows(a.Q);
+  const int nrm = a.nrm_a == nullptr ? 0 : (a.nrm_act == KK_ACT_SNAKE ? 1 : 2);
+  KKMfmaArgs g = a;
+  if (nrm == 2 && a.nrm_act != KK_ACT_LRELU) g.nrm_slope = 1.0f;  // plain AdaIN: identity activation
+  if (out_dtype != KK_BF16) {
+    if (nrm) return kk_fail("conv_mfma: fused AdaIN input needs a bf16 output");
+    return rows == 192 ? launch_one<float, 96, 0>(g, B, st) : launch_one<float, 64, 0>(g, B, st);
   }
-  if (nrm) return kk_fail("conv_mfma: fused AdaIN input needs a bf16 output");
-  return big ? launch_one<float, 128, false>(a, B, st) : launch_one<float, 64, false>(a, B, st);
+  if (rows == 192) {
+    if (nrm == 1) return launch_one<bf16_t, 96, 1>(g, B, st);
+    if (nrm == 2) return launch_one<bf16_t, 96, 2>(g, B, st);
+    return launch_one<bf16_t, 96, 0>(g, B, st);
+  }
+  if (nrm == 1) return launch_one<bf16_t, 64, 1>(g, B, st);
+  if (nrm == 2) return launch_one<bf16_t, 64, 2>(g, B, st);
+  return launch_one<bf16_t, 64, 0>(g, B, st);
 }
