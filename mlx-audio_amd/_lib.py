@@ -73,12 +73,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("KK_HIP_LIB", LIB_PATH)  # instrumented side builds only (build.py --trace)
+    if not os.path.exists(path):
         raise KokoroHipError(
-            f"{LIB_PATH} not found: build it with `python mlx-audio_amd/build.py` (hipcc, gfx950). "
+            f"{path} not found: build it with `python mlx-audio_amd/build.py` (hipcc, gfx950). "
             "The Kokoro hot path has no CPU or PyTorch fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res

@@ -36,16 +36,18 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = OUT, obj_dir: str = OBJ) -> str:
+    """extra_flags / out / obj_dir: instrumented side builds (tools/bench_conv.py --trace); the shipped library uses none."""
+    OUT, OBJ = out, obj_dir
     stamp = os.path.join(OBJ, "digest.txt")
-    dig = _digest()
+    dig = _digest() + " ".join(extra_flags)
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
         return OUT
     os.makedirs(OBJ, exist_ok=True)
 
     def cc(src):
         obj = os.path.join(OBJ, src[:-4] + ".o")
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -65,4 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--trace" in sys.argv:  # phase-timing build of the MFMA conv kernel, loaded with KK_HIP_LIB=<path>
+        build(force="--force" in sys.argv, extra_flags=("-DKK_MFMA_TRACE",), out=os.path.join(HERE, "libkokoro_hip_trace.so"),
+              obj_dir=os.path.join(CSRC, "_obj_trace"))
+    else:
+        build(force="--force" in sys.argv)

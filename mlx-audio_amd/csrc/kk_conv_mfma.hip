@@ -25,6 +25,31 @@
 #include "kk_common.h"
 #include "kk_kernels.h"
 
+#ifdef KK_MFMA_TRACE
+// phase timing of wave 0 of every workgroup (tools/bench_conv.py --trace; never compiled into the shipped library)
+__device__ unsigned long long kk_mfma_trace_acc[1024][8];  // spread over 1024 rows: same-address atomics would serialise
+#define TR_NOW() (__builtin_readcyclecounter())
+#define TR_ADD(slot, v) \
+  do { if (threadIdx.x == 0) atomicAdd(&kk_mfma_trace_acc[(blockIdx.x + 37 * blockIdx.z) & 1023][slot], (unsigned long long)(v)); } while (0)
+extern "C" int kk_debug_mfma_trace(unsigned long long* out8, int reset) {
+  static unsigned long long h[1024][8];
+  if (out8) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kk_mfma_trace_acc), sizeof(h)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (int r = 0; r < 1024; ++r)
+      for (int k = 0; k < 8; ++k) out8[k] += h[r][k];
+  }
+  if (reset) {
+    for (int r = 0; r < 1024; ++r)
+      for (int k = 0; k < 8; ++k) h[r][k] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kk_mfma_trace_acc), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define TR_NOW() 0ull
+#define TR_ADD(slot, v) do { } while (0)
+#endif
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -96,6 +121,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int op_first = a.mode == KK_CONV ? q0 : phase + a.stride * q0;
   const bool tile_live = op_first < Lout;  // uniform over the workgroup
 
+  const unsigned long long tr0 = TR_NOW();
+  unsigned long long tr_sx = 0, tr_sw = 0;
+  (void)tr0; (void)tr_sx; (void)tr_sw;
   f32x16 acc[MI][2];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -235,6 +263,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     store_x(0);
     __syncthreads();
     if (nit > 1) load_w(1);
+    const unsigned long long tr1 = TR_NOW();
+    (void)tr1;
+    TR_ADD(0, tr1 - tr0);  // prologue: first X slab + first W tile on chip
 
     const int arow = wr * WM + (lane & 31);  // + mi*32 + tap shift
     const int brow = wc * 64 + (lane & 31);  // + ni*32
@@ -261,18 +292,44 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[mi][1], 0, 0, 0);
         }
       }
+#ifndef KK_MFMA_NO_SGB
+      // prescribe the issue order: the fragments of k-step ks+1 are read from LDS WHILE the MFMAs of k-step ks run.  Left to
+      // itself hipcc issues all 4 k-steps' ds_reads first and the 24 MFMAs after them, and the waves of a CU then fall into
+      // lock step (everyone reads LDS, then everyone computes): measured 2860 cycles per iteration = LDS time + MFMA time.
+      {
+        constexpr int NF = 2 + MI, NM = 2 * MI;
+        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+#pragma unroll
+        for (int ks = 0; ks < CK / 16 - 1; ++ks) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      }
+#endif
       if (it + 1 < nit) {
+        const unsigned long long ta = TR_NOW();
         store_w((it & 1) ? Ws0 : Ws1);  // buffer last read in iteration it-1; every wave has passed that barrier
         if (tap == 0 && chunk + 1 < nchunk) store_p(chunk + 1);  // parameter loads were issued with load_x above
+        const unsigned long long tb = TR_NOW();
+        tr_sw += tb - ta;
         if (last_tap) {
           __syncthreads();  // all waves are done with the X slab
           store_x(chunk + 1);
+          tr_sx += TR_NOW() - tb;
         }
         __syncthreads();
         if (it + 2 < nit) load_w(it + 2);
       }
     }
     __syncthreads();  // main-loop LDS is dead; the epilogue tile aliases it
+    TR_ADD(1, TR_NOW() - tr1);  // main loop
+    TR_ADD(2, tr_sw);           //   of which: waiting for + storing the prefetched W tile
+    TR_ADD(3, tr_sx);           //   of which: barrier + transform + store of the next X slab
   }
 
   // ---- epilogue: per 128 rows, accumulators -> fp32 LDS tile -> coalesced rows --------------------------------------
@@ -290,6 +347,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int k = 0; k < 8; ++k) st_s[k] = st_q[k] = 0.f;
 
   constexpr int RPP = G::RPP, NPASS = BM / RPP, TASKS = RPP * 16 / 256, TG = TASKS / 2;  // 8 or 6 row tasks per thread and pass
+  // bf16 residual rows of the WHOLE tile are requested up front (xreg / w registers are dead by now): one exposed HBM
+  // round trip per tile instead of one per (pass, half)
+  constexpr bool PRE = sizeof(TO) == 2;
+  uint4 rpre[PRE ? NPASS * 2 * TG : 1];
+  if (PRE && rb) {
+#pragma unroll
+    for (int j = 0; j < NPASS * 2 * TG; ++j) {
+      const int q = q0 + (j / (2 * TG)) * RPP + (((j % (2 * TG)) * 256 + tid) >> 4);
+      const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
+      const int opc = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
+      rpre[j] = *(const uint4*)(rb + (long long)opc * a.ldr + nc);
+    }
+    asm volatile("" ::: "memory");
+  }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     if (tile_live) {
@@ -308,6 +379,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
       __syncthreads();
     }
+    if (pass == 0) TR_ADD(6, TR_NOW() - tr0);  // .. first accumulator tile is in LDS (residual requests issued)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       int opv[TG];
@@ -324,9 +396,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
       if (rb) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < TG; ++i)
+        for (int i = 0; i < TG; ++i) {
+          if (PRE) rres[i][0] = rpre[(pass * 2 + half) * TG + i];
+          else
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
+            for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
+        }
       }
       if (a.accumulate) {
 #pragma unroll
@@ -412,7 +487,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
       }
     }
+    if (pass == 0) TR_ADD(7, TR_NOW() - tr0);  // .. first pass stored
   }
+  TR_ADD(4, TR_NOW() - tr0);  // start .. end of the store phase
+  TR_ADD(5, 1);
   if (a.stat_part) {
     // rows of one column group live in threads tid = rg*16 + cg: reduce rg over the wave by shuffles (xor 16, 32),
     // then over the 4 waves through LDS; one deterministic partial per (utterance, tile, column)

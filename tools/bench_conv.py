@@ -65,9 +65,23 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    trace = None
+    if hasattr(lib, "kk_debug_mfma_trace") and os.environ.get("KK_HIP_LIB"):
+        # phase timing (build.py --trace): mean cycles of wave 0 per workgroup
+        buf = (C.c_ulonglong * 8)()
+        lib.kk_debug_mfma_trace(None, 1)
+        call()
+        torch.cuda.synchronize()
+        lib.kk_debug_mfma_trace(buf, 1)
+        n = max(1, buf[5])
+        trace = {"blocks": int(buf[5]), "prologue": buf[0] // n, "main_loop": buf[1] // n, "main.w_wait_store": buf[2] // n,
+                 "main.x_barrier_transform": buf[3] // n, "epi.acc_in_lds": buf[6] // n, "epi.pass0_stored": buf[7] // n, "total_to_store_end": buf[4] // n}
     fl = 2.0 * B * L * Cin * Cout * K
     by = B * L * (Cin + Cout * (2 if res else 1)) * 2
-    return {"name": name + ("+fused" if fused else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+    out = {"name": name + ("+fused" if fused else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+    if trace:
+        out["trace_cycles"] = trace
+    return out
 
 
 if __name__ == "__main__":
