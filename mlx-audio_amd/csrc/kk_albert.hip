@@ -2,8 +2,7 @@
 //   * AlbertEmbeddings (modules.py:451-465): word + position + token_type(0) -> LayerNorm(eps 1e-12)
 //   * AlbertSelfAttention core (modules.py:497-512): softmax(Q K^T / sqrt(64) + mask) V per head.
 // Keys past the utterance's length do not exist in the reference's batch-1 call; here they are
-// simply not visited.  One workgroup per (utterance, head); each thread owns one query row and
-// runs an online softmax over 64-key tiles of K/V staged in LDS (head size 64).
+// simply not visited.  One workgroup per (head, utterance, 32-query tile); see attention_kernel.
 #include "kk_common.h"
 #include "kk_kernels.h"
 
@@ -54,69 +53,103 @@ __global__ __launch_bounds__(256) void albert_embed_kernel(KKEmbedArgs a) {
   }
 }
 
-constexpr int HD = 64, KT = 64;
+constexpr int HD = 64, QT = 32, KP = 8, KC = 128, KLD = 68;  // 32 queries x 8 key partitions per workgroup, 128-key chunks
+constexpr int ATT_LDS = 2 * KC * KLD * 4;
 
+// One workgroup per (head, utterance, 32-query tile).  Thread (qi, part) owns query qi and the keys k = part (mod 8): its own
+// online softmax over ~L/8 keys, then the 8 partials of a query (adjacent lanes) are merged with shuffles.  K / V chunks sit in
+// LDS as fp32 rows of 68 floats: the 8 partitions of a wave read 8 consecutive rows (16 B each, bank offset 4 per row ->
+// conflict-free) and the 8 queries sharing a partition read the same address (broadcast).
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(KKAttnArgs a) {
-  // every lane reads the SAME key row (broadcast), so no padding is needed and rows can be read as float4
-  __shared__ __attribute__((aligned(16))) float Ks[KT][HD];
-  __shared__ __attribute__((aligned(16))) float Vs[KT][HD];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y, h = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  float* Ks = att_lds;
+  float* Vs = att_lds + KC * KLD;
+  const int tid = threadIdx.x, part = tid & (KP - 1), ql = tid >> 3;
+  const int h = blockIdx.x, b = blockIdx.y, qi = blockIdx.z * QT + ql;
   const int L = kk_len(a.len, b);
   const T* base = (const T*)a.qkv + (long long)b * a.bs;
   T* ob = (T*)a.out + (long long)b * a.obs;
   const int qoff = h * HD, koff = a.hs + h * HD, voff = 2 * a.hs + h * HD;
-  for (int q0 = 0; q0 < a.Tmax; q0 += 256) {
-    const int qi = q0 + tid;
-    const bool qv = qi < L;
-    float q[HD], o[HD];
+  const bool qv = qi < L;
+  if (blockIdx.z * QT >= L) {  // whole tile is past the utterance: rows are zero (uniform over the workgroup)
+    if (qi < a.Tmax)
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      q[d] = qv ? kk_ld(base + (long long)qi * a.ld + qoff + d) * a.scale : 0.f;
-      o[d] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < L; k0 += KT) {
-      __syncthreads();
-      for (int e = tid; e < KT * HD; e += 256) {
-        const int kr = e / HD, d = e - kr * HD;
-        const int ki = k0 + kr;
-        Ks[kr][d] = ki < L ? kk_ld(base + (long long)ki * a.ld + koff + d) : 0.f;
-        Vs[kr][d] = ki < L ? kk_ld(base + (long long)ki * a.ld + voff + d) : 0.f;
+      for (int d = 0; d < 8; ++d) kk_st(ob + (long long)qi * a.ldo + qoff + part * 8 + d, 0.f);
+    return;
+  }
+  float q[HD], o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] = qv ? kk_ld(base + (long long)qi * a.ld + qoff + d) * a.scale : 0.f;
+    o[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < L; k0 += KC) {
+    if (k0 > 0) __syncthreads();
+    for (int e = tid; e < KC * (HD / 4); e += 256) {
+      const int kr = e >> 4, d = (e & 15) * 4;
+      const int ki = k0 + kr;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (ki < L) {
+        const T* kp = base + (long long)ki * a.ld + koff + d;
+        const T* vp = base + (long long)ki * a.ld + voff + d;
+        kv = make_float4(kk_ld(kp), kk_ld(kp + 1), kk_ld(kp + 2), kk_ld(kp + 3));
+        vv = make_float4(kk_ld(vp), kk_ld(vp + 1), kk_ld(vp + 2), kk_ld(vp + 3));
       }
-      __syncthreads();
-      const int kn = min(KT, L - k0);
-      for (int kr = 0; kr < kn; ++kr) {
-        float s = 0.f;
+      *(float4*)(Ks + kr * KLD + d) = kv;
+      *(float4*)(Vs + kr * KLD + d) = vv;
+    }
+    __syncthreads();
+    const int kn = min(KC, L - k0);
+    for (int kr = part; kr < kn; kr += KP) {
+      const float* krow = Ks + kr * KLD;
+      const float* vrow = Vs + kr * KLD;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          const float4 k4 = *(const float4*)&Ks[kr][d];
-          s = __builtin_fmaf(q[d], k4.x, s);
-          s = __builtin_fmaf(q[d + 1], k4.y, s);
-          s = __builtin_fmaf(q[d + 2], k4.z, s);
-          s = __builtin_fmaf(q[d + 3], k4.w, s);
-        }
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn);
-        const float p = expf(s - mn);
-        l = l * corr + p;
-#pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          const float4 v4 = *(const float4*)&Vs[kr][d];
-          o[d] = __builtin_fmaf(p, v4.x, o[d] * corr);
-          o[d + 1] = __builtin_fmaf(p, v4.y, o[d + 1] * corr);
-          o[d + 2] = __builtin_fmaf(p, v4.z, o[d + 2] * corr);
-          o[d + 3] = __builtin_fmaf(p, v4.w, o[d + 3] * corr);
-        }
-        m = mn;
+      for (int d = 0; d < HD; d += 4) {
+        const float4 k4 = *(const float4*)(krow + d);
+        s0 = __builtin_fmaf(q[d], k4.x, s0);
+        s1 = __builtin_fmaf(q[d + 1], k4.y, s1);
+        s2 = __builtin_fmaf(q[d + 2], k4.z, s2);
+        s3 = __builtin_fmaf(q[d + 3], k4.w, s3);
       }
-    }
-    if (qi < a.Tmax) {
-      const float inv = (qv && l > 0.f) ? 1.0f / l : 0.f;
+      const float sc = (s0 + s1) + (s2 + s3);
+      const float mn = fmaxf(m, sc);
+      const float corr = expf(m - mn);
+      const float p = expf(sc - mn);
+      l = l * corr + p;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) kk_st(ob + (long long)qi * a.ldo + qoff + d, qv ? o[d] * inv : 0.f);
+      for (int d = 0; d < HD; d += 4) {
+        const float4 v4 = *(const float4*)(vrow + d);
+        o[d] = __builtin_fmaf(p, v4.x, o[d] * corr);
+        o[d + 1] = __builtin_fmaf(p, v4.y, o[d + 1] * corr);
+        o[d + 2] = __builtin_fmaf(p, v4.z, o[d + 2] * corr);
+        o[d + 3] = __builtin_fmaf(p, v4.w, o[d + 3] * corr);
+      }
+      m = mn;
     }
+  }
+  // merge the 8 partials of this query (lanes part = 0..7 are adjacent)
+  float mg = m;
+#pragma unroll
+  for (int x = 1; x < KP; x <<= 1) mg = fmaxf(mg, __shfl_xor(mg, x));
+  const float w = (m == -INFINITY) ? 0.f : expf(m - mg);  // a partition that saw no key contributes nothing
+  l *= w;
+#pragma unroll
+  for (int x = 1; x < KP; x <<= 1) l += __shfl_xor(l, x);
+  const float inv = (qv && l > 0.f) ? 1.0f / l : 0.f;
+  float mine[8];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    float v = o[d] * w;
+#pragma unroll
+    for (int x = 1; x < KP; x <<= 1) v += __shfl_xor(v, x);
+    if ((d >> 3) == part) mine[d & 7] = v;  // lane `part` keeps dims 8*part .. 8*part+7
+  }
+  if (qi < a.Tmax) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) kk_st(ob + (long long)qi * a.ldo + qoff + part * 8 + d, qv ? mine[d] * inv : 0.f);
   }
 }
 
@@ -137,11 +170,17 @@ int kk_launch_albert_embed(const KKEmbedArgs& a, int B, int dtype, hipStream_t s
 int kk_launch_attention(const KKAttnArgs& a, int B, int dtype, hipStream_t st) {
   if (B <= 0 || a.Tmax <= 0) return 0;
   if (a.hs != a.heads * HD) return kk_fail("attention: head size must be 64");
-  dim3 grid(a.heads, B);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attention_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    attr_done = true;
+  }
+  dim3 grid(a.heads, B, kk_cdiv(a.Tmax, QT));
   if (dtype == KK_F32)
-    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), ATT_LDS, st, a);
   else
-    hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), ATT_LDS, st, a);
   KK_CHECK_LAUNCH();
   return 0;
 }
