@@ -190,21 +190,23 @@ __global__ __launch_bounds__(256) void stft20_kernel(const float* hs, int Nmax, 
 
 // ------------------------------------------------------------------ iSTFT head
 // HBM-bound by design: 22 inputs and 5 fp32 outputs per frame column (64 B with bf16 input).
-//   phase 0  the workgroup's [259 frames][ldx] input tile is ONE contiguous span: coalesced 16-byte loads into LDS
+//   phase 0  the workgroup's [255 frames][ldx] input tile is ONE contiguous span: coalesced 16-byte loads into LDS
 //   phase 1  one thread per frame: exp / sin / sincos, then the 20-point inverse real DFT using the o <-> 20-o symmetry
 //            (cos terms even, sin terms odd: 11 x 18 FMAs instead of 20 x 18), x periodic Hann -> LDS
 //   phase 2  one thread per hop block: <= 4 overlapping frames added in ascending frame order (the reference's
 //            scatter-add order, utils.py:138-147), divided by the window sum accumulated in the same order
-//   phase 3  the 1280 output samples of the workgroup leave as coalesced 8-byte stores
-constexpr int IH_FR = 256;  // hop-blocks per workgroup
+//   phase 3  the 1260 output samples of the workgroup leave as coalesced 8-byte stores
+// 252 hop blocks + 3 halo frames = 255 frames: ONE frame per thread in phase 1 (with 256 + 3 the second trip of the frame loop
+// ran a full pass for three frames and doubled the kernel's VALU time); 252 * 5 samples keeps every workgroup's first sample even
+constexpr int IH_FR = 252;  // hop-blocks per workgroup
 constexpr int IH_NF = IH_FR + 3;
 
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
                                                          long long wbs, Tables tb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ism[];
-  float* ys = (float*)ism;                          // [259][21]
-  unsigned char* tile = ism + IH_NF * 21 * 4;       // [259][ldx] input tile, later the output staging
+  float* ys = (float*)ism;                          // [255][21]
+  unsigned char* tile = ism + IH_NF * 21 * 4;       // [255][ldx] input tile, later the output staging
   const int b = blockIdx.y, tid = threadIdx.x;
   const int Tf = len_frames ? len_frames[b] : Tfmax;
   const int g0 = blockIdx.x * IH_FR;  // first hop-block of this workgroup
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
     }
   }
   __syncthreads();
-  // ---- phase 1: windowed inverse real DFT of frames f0 .. f0+258
+  // ---- phase 1: windowed inverse real DFT of frames f0 .. f0+254
   for (int i = tid; i < IH_NF; i += 256) {
     const int f = f0 + i;
     float* yo = ys + i * 21;
@@ -244,19 +246,37 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
         re[k] = mag * c;
         im[k] = mag * s;
       }
-      // x[o] = (re0 + (-1)^o re10 + 2 (C[o] - S[o])) / 20,  x[20-o] = (.. + 2 (C[o] + S[o])) / 20
+      // x[o] = (re0 + (-1)^o re10 + 2 (C[o] - S[o])) / 20,  x[20-o] = (.. + 2 (C[o] + S[o])) / 20  with
+      //   C[o] = sum_k re[k] cos(2 pi k o / 20),  S[o] = sum_k im[k] sin(2 pi k o / 20),  k = 1..9.
+      // Even / odd k split: cos(2 pi k (10-o)/20) = (-1)^k cos(..o..), sin(2 pi k (10-o)/20) = -(-1)^k sin(..o..), so
+      // o and 10-o share their partial sums: 6 x 18 FMAs instead of 11 x 18.
 #pragma unroll
-      for (int o = 0; o <= 10; ++o) {
-        float C = 0.f, S = 0.f;
+      for (int o = 0; o <= 5; ++o) {
+        float Ce = 0.f, Co = 0.f, Se = 0.f, So = 0.f;
 #pragma unroll
         for (int k = 1; k < 10; ++k) {
           const int m = (k * o) % 20;
-          C = __builtin_fmaf(re[k], tb.cs[m], C);
-          S = __builtin_fmaf(im[k], tb.sn[m], S);
+          if (k & 1) {
+            Co = __builtin_fmaf(re[k], tb.cs[m], Co);
+            So = __builtin_fmaf(im[k], tb.sn[m], So);
+          } else {
+            Ce = __builtin_fmaf(re[k], tb.cs[m], Ce);
+            Se = __builtin_fmaf(im[k], tb.sn[m], Se);
+          }
         }
-        const float dc = re[0] + ((o & 1) ? -re[10] : re[10]);
-        yo[o] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[o];
-        if (o > 0 && o < 10) yo[20 - o] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - o];
+        {
+          const float C = Ce + Co, S = Se + So;
+          const float dc = re[0] + ((o & 1) ? -re[10] : re[10]);
+          yo[o] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[o];
+          if (o > 0) yo[20 - o] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - o];
+        }
+        if (o < 5) {
+          const int p = 10 - o;
+          const float C = Ce - Co, S = So - Se;
+          const float dc = re[0] + ((p & 1) ? -re[10] : re[10]);
+          yo[p] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[p];
+          if (p < 10) yo[20 - p] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - p];
+        }
       }
     } else {
 #pragma unroll
@@ -265,11 +285,12 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
   }
   __syncthreads();
   // ---- phase 2: overlap-add in ascending frame order, normalise by the window sum, trim 10 | 10
-  float* stage = (float*)tile;  // [256][5]
+  float* stage = (float*)tile;  // [252][5]
   const int g = g0 + tid;
   const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
+    if (tid >= IH_FR) break;
     const int n = 5 * g + r - 10;
     float v = 0.f;
     if (n >= 0 && n < nout) {
@@ -282,12 +303,12 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
           ws += tb.hann_per[5 * j + r];
         }
       }
-      v = ws != 0.f ? acc / ws : acc;
+      v = ws != 0.f ? (FAST ? acc * __builtin_amdgcn_rcpf(ws) : acc / ws) : acc;
     }
     stage[tid * 5 + r] = v;
   }
   __syncthreads();
-  // ---- phase 3: samples n0 .. n0+1279 (n0 = 5*g0 - 10, even) as float2 stores
+  // ---- phase 3: samples n0 .. n0+1259 (n0 = 5*g0 - 10, even) as float2 stores
   float* wb = wav + (long long)b * wbs;
   const long long n0 = 5LL * g0 - 10;
   const long long ntot = 5LL * (Tfmax - 1);
