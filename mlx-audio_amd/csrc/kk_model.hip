@@ -130,6 +130,8 @@ struct kk_model {
   VecW lin_w;
   float lin_b = 0.f;
   ConvW noise_conv[4], ups[4], conv_post;
+  ConvW noise_conv_rows[4];  // bf16 mode: the strided noise convs re-expressed as stride-1 convs over row groups (Packer::strided_rows)
+  int noise_rows_pad[4] = {0, 0, 0, 0};
   ResBlock1 noise_res[4];
   std::vector<ResBlock1> resblocks;
   // style projections (all AdaIN / AdaLN fc's), one matrix per style half
@@ -383,6 +385,41 @@ struct Packer {
     if (!vec(prefix + ".bias", (size_t)O, b)) return ConvW();
     return pack_oki(w, O, K, I, &b);
   }
+  // A strided conv (stride s, kernel K, padding pad) over rows of pitch `ld` reads, for output row q, the input rows
+  // s*q - pad .. s*q - pad + K - 1: whole or partial GROUPS of s consecutive rows.  Viewing the input as rows of s*ld
+  // channels turns it into a stride-1 conv with K2 = tau_max - tau_min + 1 taps (tau = floor((t - pad) / s)) whose weights are
+  // the original taps scattered into [tau][co][j*ld + c] (zero elsewhere) -- which the MFMA kernel can run (noise_convs,
+  // istftnet.py:744-752: Conv1d(22, 256, k=12, stride=6, padding=3) becomes 3 taps x 384 channels).  bf16 pack only.
+  ConvW strided_rows(const std::string& prefix, int O, int K, int I, int s, int pad, int ld, int* pad2) {
+    ConvW c;
+    if (m->adt != KK_BF16) return c;
+    std::vector<float> w, b;
+    if (!conv3(prefix + ".weight", O, K, I, w)) return ConvW();
+    if (!vec(prefix + ".bias", (size_t)O, b)) return ConvW();
+    auto fdiv = [](int a, int d) { return a >= 0 ? a / d : -((-a + d - 1) / d); };
+    const int tmin = fdiv(-pad, s), tmax = fdiv(K - 1 - pad, s);
+    const int K2 = tmax - tmin + 1, I2 = s * ld;
+    *pad2 = -tmin;
+    c.Cin = I2; c.Cout = O; c.Kw = K2; c.ldw = 0;
+    c.mfma = true;
+    c.Cout8 = kk_cdiv(O, 8) * 8;
+    c.CinP = kk_cdiv(I2, 64) * 64;
+    c.CoutP = kk_cdiv(O, 128) * 128;
+    const size_t nel = (size_t)K2 * c.CoutP * c.CinP;
+    c.wb_off = alloc((nel + 1) / 2);
+    uint16_t* dst = (uint16_t*)&m->pack[c.wb_off];
+    memset(dst, 0, nel * 2);
+    for (int o = 0; o < O; ++o)
+      for (int t = 0; t < K; ++t) {
+        const int tau = fdiv(t - pad, s), j = (t - pad) - tau * s;
+        for (int i = 0; i < I; ++i)
+          dst[((size_t)(tau - tmin) * c.CoutP + o) * c.CinP + j * ld + i] = f32_to_bf16_rne(w[((size_t)o * K + t) * I + i]);
+      }
+    c.has_bias = true;
+    c.b_off = alloc(c.CoutP);
+    memcpy(&m->pack[c.b_off], b.data(), (size_t)O * 4);
+    return c;
+  }
   // nn.Linear: weight [O][I], bias [O]
   ConvW linear(const std::string& prefix, int O, int I) {
     std::vector<float> w, b;
@@ -600,6 +637,7 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
       int sf0 = 1;
       for (int j = i + 1; j < c.n_upsamples; ++j) sf0 *= c.upsample_rates[j];
       m->noise_conv[i] = P.conv_plain(g + "noise_convs." + is, cout, sf0 * 2, c.gen_istft_n_fft + 2);
+      m->noise_conv_rows[i] = P.strided_rows(g + "noise_convs." + is, cout, sf0 * 2, c.gen_istft_n_fft + 2, sf0, (sf0 + 1) / 2, 64, &m->noise_rows_pad[i]);
       m->noise_res[i] = build_resblock1(P, SD, g + "noise_res." + is, cout, 7, d135);
     } else {
       m->noise_conv[i] = P.conv_plain(g + "noise_convs." + is, cout, 1, c.gen_istft_n_fft + 2);
@@ -635,7 +673,7 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   for (auto& v : m->te_ln_b) resolve(m, v);
   resolve(m, m->enc);
   for (int i = 0; i < 4; ++i) resolve(m, m->dec[i]);
-  for (int i = 0; i < c.n_upsamples; ++i) { resolve(m, m->noise_conv[i]); resolve(m, m->ups[i]); resolve(m, m->noise_res[i]); }
+  for (int i = 0; i < c.n_upsamples; ++i) { resolve(m, m->noise_conv[i]); resolve(m, m->noise_conv_rows[i]); resolve(m, m->ups[i]); resolve(m, m->noise_res[i]); }
   for (auto& r : m->resblocks) resolve(m, r);
   m->host.clear();
   m->pack.clear();
@@ -685,6 +723,7 @@ struct ConvOpt {
   int nrm_C = 0;
   bool want_stats = false;
   bool pad_out_ok = false;  // the destination may receive up to 7 extra zero channels (Cout rounded up to 8)
+  double alg_taps_cin = 0;  // algorithmic taps*Cin of the op this launch implements, when the packed form carries structural zeros
 };
 
 struct Ctx {
@@ -754,7 +793,7 @@ struct Ctx {
     // algorithmic work of this launch at full length: every output row sums Kw*Cin (conv) or Kw/stride*Cin (convT) products
     const double rows_out = o.mode == KK_CONVT ? (double)Q * o.stride : (double)Q;
     const double taps = o.mode == KK_CONVT ? (double)w.Kw / o.stride : (double)w.Kw;
-    const double flops = 2.0 * B * rows_out * w.Cout * w.Cin * taps;
+    const double flops = 2.0 * B * rows_out * w.Cout * (o.alg_taps_cin > 0 ? o.alg_taps_cin : w.Cin * taps);
     const double bytes = B * (rows_out * w.Cout * esz(out.dtype) * (o.res ? 2.0 : 1.0) + (double)Q * (o.mode == KK_CONVT ? 1 : o.stride) * w.Cin * esz(x.dtype)) +
                          (double)w.Kw * w.Cin * w.Cout * 4.0;
     if (can_mfma(w, x, out, o)) {
@@ -1225,7 +1264,9 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   // ---- Generator front end (istftnet.py:770-775)
   float* phase = c.f32((size_t)B * 9 * L2);
   float* har_source = c.f32((size_t)B * Nw);
-  Buf har = c.act(Tf, c.adt == KK_BF16 ? 64 : 24);  // bf16: pitch 64 so the k=1 noise conv can run on the MFMA kernel
+  // bf16: pitch 64 so the k=1 noise conv can run on the MFMA kernel; 16 spare (zero) rows so the strided noise convs can
+  // read whole row groups (Packer::strided_rows)
+  Buf har = c.act(c.adt == KK_BF16 ? Tf + 16 : Tf, c.adt == KK_BF16 ? 64 : 24);
   if (!c.dry && c.adt == KK_BF16 && hipMemsetAsync(har.p, 0, (size_t)B * har.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
   if (!c.dry) {
     KKSourceArgs sa;
@@ -1260,7 +1301,20 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
       on.stride = sf0;
       on.pad = (sf0 + 1) / 2;
     }
-    KK_TRY(c.conv(m->noise_conv[i], har, lTf, xsrc, lst, Lst, on));
+    const ConvW& nrows = m->noise_conv_rows[i];
+    if (!last && nrows.mfma && c.adt == KK_BF16 && !m->force_generic && har.ld == 64 && on.stride <= 16 && nrows.Cin == on.stride * har.ld) {
+      // stride-1 form over groups of `stride` rows (see Packer::strided_rows): valid groups = ceil(len / stride) = lst + 1
+      Buf hg = har;
+      hg.ld = on.stride * har.ld;
+      hg.rows = har.rows / on.stride;
+      ConvOpt og;
+      og.pad = m->noise_rows_pad[i];
+      og.alg_taps_cin = (double)m->noise_conv[i].Kw * m->noise_conv[i].Cin;
+      const KKLen lg = {lst.len, lst.mul, lst.add + 1};
+      KK_TRY(c.conv(nrows, hg, lg, xsrc, lst, Lst, og));
+    } else {
+      KK_TRY(c.conv(m->noise_conv[i], har, lTf, xsrc, lst, Lst, on));
+    }
     KK_TRY(run_resblock1(c, m->noise_res[i], xsrc, xsrc, t1, t2, Lst, lst, style_d, m->Nd, nullptr, 1.f, 0));
     ConvOpt ou;
     ou.mode = KK_CONVT;
