@@ -3,10 +3,17 @@
 //   * AlbertSelfAttention core (modules.py:497-512): softmax(Q K^T / sqrt(64) + mask) V per head.
 // Keys past the utterance's length do not exist in the reference's batch-1 call; here they are
 // simply not visited.  One workgroup per (head, utterance, 32-query tile); see attention_kernel.
+#include <stdlib.h>
+
 #include "kk_common.h"
 #include "kk_kernels.h"
 
 namespace {
+
+union U16 {
+  uint4 u;
+  bf16_t h[8];
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void albert_embed_kernel(KKEmbedArgs a) {
@@ -153,6 +160,135 @@ __global__ __launch_bounds__(256) void attention_kernel(KKAttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode: flash-style attention on the matrix cores, ONE WAVE per (head, utterance, 32-query tile), no barriers
+// between waves, 4.6 KB LDS.  Per 32-key tile:
+//   S^T[key][q]  = K[key][:] . Q[q][:]          4 x mfma_32x32x16 (A = K rows straight from global, B = Q rows, loaded once)
+//   online softmax per query: in the S^T accumulator layout a lane owns ONE query column (its 16 keys in registers, the other
+//   16 in lane ^ 32), so max / sum are register reductions plus one shuffle and the rescale factor is per lane
+//   O^T[d][q]   += V^T[d][key] . P^T[key][q]    4 x mfma (2 d-tiles x 2 k-steps).  P^T is the accumulator itself: MFMA k-slot
+//   (half h, j) of k-step s is DEFINED as the key the lane already holds in register 8s + j, i.e. key = (j&3) + 4h + 8(j>>2) +
+//   16s -- a fixed permutation of the 32 keys, applied to V^T when its tile is transposed through LDS (key bits 2 and 3 swap).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x16 __attribute__((ext_vector_type(16)));
+constexpr int VT_LD = 40;  // bf16 elements per V^T row in LDS (32 keys + 8 pad: 80-byte pitch, 16-byte aligned, conflict-light)
+
+__global__ __launch_bounds__(64) void attention_mfma_kernel(KKAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t vt[64 * VT_LD];
+  const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.x, b = blockIdx.y, q0 = blockIdx.z * 32;
+  const int L = kk_len(a.len, b);
+  const bf16_t* base = (const bf16_t*)a.qkv + (long long)b * a.bs;
+  bf16_t* ob = (bf16_t*)a.out + (long long)b * a.obs;
+  const int qoff = h * HD, koff = a.hs + h * HD, voff = 2 * a.hs + h * HD;
+  const int qi = q0 + c;
+  if (q0 >= L) {  // whole tile is past the utterance: rows are zero (uniform)
+    if (qi < a.Tmax) {
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(uint4*)(ob + (long long)qi * a.ldo + qoff + hh * 32 + j * 8) = z;
+    }
+    return;
+  }
+  const int qc = qi < L ? qi : L - 1;  // clamped: rows past L compute garbage-free duplicates that are never stored
+  abf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const abf16x8*)(base + (long long)qc * a.ld + qoff + ks * 16 + hh * 8);
+
+  af32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float sc = a.scale * 1.4426950408889634f;  // softmax in base 2: exp(x) = exp2(x * log2 e)
+
+  for (int k0 = 0; k0 < L; k0 += 32) {
+    // K fragments of this tile: lane = key row (clamped), 8 consecutive d per k-step
+    const int kr = k0 + c < L ? k0 + c : L - 1;
+    abf16x8 kf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const abf16x8*)(base + (long long)kr * a.ld + koff + ks * 16 + hh * 8);
+    // V tile [32 keys][64 d]: lane loads keys (lane >> 3) + 8 i, d chunk (lane & 7) * 8
+    uint4 vreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = k0 + (lane >> 3) + 8 * i;
+      const int kc = key < L ? key : L - 1;
+      vreg[i] = *(const uint4*)(base + (long long)kc * a.ld + voff + (lane & 7) * 8);
+    }
+    af32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+    // scores of query c against keys k0 + (r&3) + 8(r>>2) + 4hh
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      st[r] = key < L ? st[r] * sc : -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);  // finite: every tile holds at least one valid key
+    const float corr = exp2f(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = exp2f(st[r] - mn);
+      ps += st[r];
+    }
+    l = l * corr + ps;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= corr;
+      o1[r] *= corr;
+    }
+    abf16x8 pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16_t)st[8 * s2 + j];
+    // V^T through LDS with the key permutation (bits 2 and 3 of the key index swap); keys past L carry weight exp2(-inf) = 0
+    __syncthreads();  // one wave: orders the previous tile's fragment reads before these writes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kl = (lane >> 3) + 8 * i;
+      const int kp = (kl & 0x13) | ((kl & 4) << 1) | ((kl & 8) >> 1);
+      U16 t;
+      t.u = vreg[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt[((lane & 7) * 8 + e) * VT_LD + kp] = t.h[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const abf16x8 v0 = *(const abf16x8*)(vt + c * VT_LD + s2 * 16 + hh * 8);
+      const abf16x8 v1 = *(const abf16x8*)(vt + (32 + c) * VT_LD + s2 * 16 + hh * 8);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[s2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[s2], o1, 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 32);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  if (qi < a.Tmax) {
+    const bool qv = qi < L;
+    // lane owns query c and d = 32 t + (r&3) + 8(r>>2) + 4hh: four consecutive d per register group -> 8-byte stores
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        union { uint2 u; bf16_t hv[4]; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.hv[e] = (bf16_t)(qv ? (t2 ? o1[4 * g + e] : o0[4 * g + e]) * inv : 0.f);
+        *(uint2*)(ob + (long long)qi * a.ldo + qoff + 32 * t2 + 8 * g + 4 * hh) = pk.u;
+      }
+  }
+}
+
 }  // namespace
 
 int kk_launch_albert_embed(const KKEmbedArgs& a, int B, int dtype, hipStream_t st) {
@@ -177,6 +313,13 @@ int kk_launch_attention(const KKAttnArgs& a, int B, int dtype, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(a.heads, B, kk_cdiv(a.Tmax, QT));
+  static int no_mfma = -1;
+  if (no_mfma < 0) no_mfma = getenv("KK_ATTN_VALU") ? 1 : 0;  // A/B switch: the fp32 VALU kernel also handles bf16 tensors
+  if (dtype == KK_BF16 && !no_mfma && a.ld % 8 == 0 && a.ldo % 8 == 0 && a.hs % 8 == 0 && !(((uintptr_t)a.qkv | (uintptr_t)a.out) & 15)) {
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(64), 0, st, a);
+    KK_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == KK_F32)
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), ATT_LDS, st, a);
   else

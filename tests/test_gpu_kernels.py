@@ -309,6 +309,34 @@ def test_attention(lib):
         assert np.all(got[b, n:] == 0)
 
 
+def test_attention_bf16_mfma(lib):
+    """bf16 tensors take the matrix-core kernel (one wave per 32-query tile); reference = fp32 softmax attention on the
+    same bf16-rounded inputs.  P and the output are rounded to bf16: tolerance 1.5e-2 of the tensor's max."""
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(22)
+    B, T, heads = 3, 130, 3
+    hs = heads * 64
+    lens = [130, 77, 33]
+    qkv = torch.tensor(rng.standard_normal((B, T, 3 * hs)).astype(np.float32)).to(torch.bfloat16)
+    out = torch.full((B, T, hs), 9.0, device="cuda", dtype=torch.bfloat16)
+    qd = qkv.cuda()
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_attention(stream(), B, P(qd), 3 * hs, T, P(lend), heads, P(out), hs, _lib.KK_BF16)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    for b, n in enumerate(lens):
+        t = qkv[b, :n].float()
+        q, k, v = [t[:, i * hs : (i + 1) * hs].view(n, heads, 64).permute(1, 0, 2) for i in range(3)]
+        pr = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
+        ref = (pr @ v).permute(1, 0, 2).reshape(n, hs).numpy()
+        e = err_stats(got[b, :n], ref)
+        report(f"attention_bf16_mfma/b{b}", **e)
+        assert e["rel_max"] < 1.5e-2
+        assert np.all(got[b, n:] == 0)
+
+
 def test_source_and_stft(lib):
     """SineGen + SourceModuleHnNSF + STFT(20) against the oracle with INJECTED noise.  The phase channels are
     compared where the bin magnitude is not tiny (the angle of a ~1e-7 bin is noise in any implementation)."""
