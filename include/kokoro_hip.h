@@ -100,6 +100,13 @@ int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, c
                const int32_t* forced_dur, int Fmax, int noise_mode, const float* sine_noise, uint64_t seed, void* workspace,
                size_t workspace_bytes, float* wav_out, int32_t* pred_dur_out, int32_t* nframes_out);
 
+/* Graph replay of kk_forward (off by default).  With it on, the SECOND call with an identical argument tuple (every pointer,
+ * B, Tmax, Fmax, noise_mode; the seed may differ) is captured into a hipGraph on `stream` and that call and all later ones
+ * are ONE hipGraphLaunch instead of ~450 kernel launches; results are bit-identical to the eager call.  Calls with debug
+ * overrides or an open profile run eagerly.  The reference has no counterpart (MLX builds its own lazy graph per call,
+ * kokoro.py:120-170 is re-traced every time). */
+int kk_set_graph_mode(kk_model* m, int on);
+
 const char* kk_last_error(void);
 int kk_abi_version(void);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "kk_debug_clear": (None, [_vp]),
     "kk_debug_force_generic": (None, [_vp, _i]),
     "kk_debug_set_mfma3": (None, [_i]),
+    "kk_set_graph_mode": (_i, [_vp, _i]),
     "kk_profile_begin": (_i, [_vp, _i]),
     "kk_profile_end": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int nchunk = a.CinP / CK;
     const int nit = nchunk * ntaps;
     const int lin_hi = Lin > 0 ? Lin - 1 : 0;
+    const int cin_real = a.Cin > 0 ? a.Cin : a.CinP;
 
     uint4 xreg[XREG];
     float4 preg = make_float4(0.f, 0.f, 0.f, 0.f);  // threads 0..47: one float4 of the slab's A | B | alpha
@@ -213,6 +214,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
         }
       }
+      // this thread's 8 channels are the same for all its rows; channels >= Cin are pad and may hold anything (NaN x 0 = NaN)
+      const int cfirst = chunk * CK + (tid & 7) * 8;
+      unsigned cm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cm[j] = (cfirst + 2 * j < cin_real ? 0x0000FFFFu : 0u) | (cfirst + 2 * j + 1 < cin_real ? 0xFFFF0000u : 0u);
 #pragma unroll
       for (int i = 0; i < XREG; ++i) {
         const int id = i * 256 + tid;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           U16 t;
           const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
           t.u = xreg[i];
-          t.u = make_uint4(t.u.x & msk, t.u.y & msk, t.u.z & msk, t.u.w & msk);  // padding rows stay exactly zero
+          t.u = make_uint4(t.u.x & msk & cm[0], t.u.y & msk & cm[1], t.u.z & msk & cm[2], t.u.w & msk & cm[3]);  // padding stays exactly zero
           if (a.in_slope != 1.0f) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

@@ -12,6 +12,7 @@ struct KKMfmaArgs {
   int ldx;
   const bf16_t* w;  // packed [Kw][CoutP][CinP], zero padded
   int CinP, CoutP;
+  int Cin;  // channels of x that carry data; [Cin, CinP) are masked to zero while staging (pad channels may hold anything); 0 = CinP
   const float* bias;  // [CoutP] or null
   void* out;          // bf16 or fp32
   long long obs;
@@ -201,6 +202,7 @@ struct KKSourceArgs {
   float lin_b;
   const float* noise;  // optional injected N(0,1) [B][Nmax][9]; null -> Philox (seed) or zero
   unsigned long long seed;
+  const unsigned long long* seed_dev;  // graph replay: the seed lives in device memory (null = use `seed`)
   int noise_mode;  // 0 zero, 1 injected, 2 philox
   float* har_source;  // [B][Nmax]
   int Nmax;           // 300 * L2max
@@ -214,5 +216,6 @@ int kk_launch_stft20(const float* har_source, int Nmax, const int* lenN, void* h
 int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav, long long wbs, int B,
                          int dtype, int fast, hipStream_t st);
 // dtype-converting strided copy (debug hooks)
+int kk_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st);  // one 8-byte device store (graph-replay seed)
 int kk_launch_convert(const void* src, int sdt, long long sbs, int lds, void* dst, int ddt, long long dbs, int ldd, int C, int rows, int B,
                       hipStream_t st);

@@ -239,6 +239,15 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS* src, long long s
 }
 }  // namespace
 
+namespace {
+__global__ void set_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+}  // namespace
+int kk_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st) {
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, st, dst, v);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
 int kk_launch_convert(const void* src, int sdt, long long sbs, int lds, void* dst, int ddt, long long dbs, int ldd, int C, int rows, int B,
                       hipStream_t st) {
   if (B <= 0 || rows <= 0 || C <= 0) return 0;

@@ -146,6 +146,18 @@ struct kk_model {
   bool no_fusion = false;      // tests: MFMA convs but stand-alone statistics / AdaIN kernels
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs
+  // graph replay of kk_forward (kk_set_graph_mode): one instantiated hipGraph per distinct argument tuple
+  struct GraphEntry {
+    std::vector<unsigned long long> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;  // 1 = ran eagerly once (first-launch attribute calls are done), 2 = captured
+  };
+  bool graph_mode = false;
+  std::vector<GraphEntry> graphs;
+  unsigned long long* seed_dev = nullptr;  // the Philox seed of a replayed forward
+  bool capturing = false;
+  hipStream_t cap_stream = nullptr;
   struct ProfRec { int cls; double flops; double bytes; };
   std::vector<ProfRec> prof_rec;
 };
@@ -174,6 +186,12 @@ extern "C" void kk_destroy(kk_model* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+  for (auto& g : m->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  if (m->seed_dev) (void)hipFree(m->seed_dev);
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   delete m;
 }
 
@@ -801,7 +819,7 @@ struct Ctx {
       memset(&g, 0, sizeof g);
       g.nrm_a = o.nrm_a; g.nrm_b = o.nrm_b; g.nrm_stride = fz_stride; g.nrm_act = o.nrm_act; g.nrm_slope = o.nrm_slope;
       g.nrm_alpha = o.nrm_alpha; g.nrm_C = o.nrm_C;
-      g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.CoutP = w.CoutP; g.bias = w.b;
+      g.x = (const bf16_t*)x.p; g.xbs = x.bs; g.ldx = x.ld; g.w = w.wb; g.CinP = w.CinP; g.Cin = w.Cin; g.CoutP = w.CoutP; g.bias = w.b;
       g.out = out.p; g.obs = out.bs; g.ldo = out.ld;
       if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
       g.Cout = w.Cout8; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
@@ -1272,7 +1290,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     KKSourceArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.f0 = (const float*)f0n[0].p; sa.L2max = L2; sa.len2 = lens4; sa.phase = phase; sa.lin_w = m->lin_w.p; sa.lin_b = m->lin_b;
-    sa.noise = noise; sa.seed = seed; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
+    sa.noise = noise; sa.seed = seed; sa.seed_dev = m->capturing ? m->seed_dev : nullptr; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
     c.prof_start();
     KK_TRY(kk_launch_source(sa, B, c.st));
     c.prof_stop(8, 0.0, (double)B * Nw * 4.0);
@@ -1422,11 +1440,76 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
   if (!ids || !lens || !ref_s || !speed || !wav_out || Fmax <= 0) return kk_fail("kk_forward: bad argument");
   if (noise_mode == KK_NOISE_INJECTED && !sine_noise) return kk_fail("kk_forward: KK_NOISE_INJECTED needs sine_noise");
   if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, Fmax)) return kk_fail("kk_forward: workspace too small");
-  Ctx c;
-  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
-  TextState ts;
-  KK_TRY(run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out));
-  return run_audio(c, Tmax, lens, ref_s, forced_dur ? forced_dur : ts.pred_dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
+  auto eager = [&](void* on_stream) -> int {
+    Ctx c;
+    KK_TRY(make_ctx(m, on_stream, B, workspace, workspace_bytes, c));
+    TextState ts;
+    KK_TRY(run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out));
+    return run_audio(c, Tmax, lens, ref_s, forced_dur ? forced_dur : ts.pred_dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
+  };
+  // ---- graph replay: ~450 launches become one hipGraphLaunch.  Only for the plain forward: no debug overrides, no profiling.
+  if (!m->graph_mode || m->prof_on || !m->dbg_over.empty()) return eager(stream);
+  hipStream_t st = (hipStream_t)stream;
+  const std::vector<unsigned long long> key = {(unsigned long long)B, (unsigned long long)Tmax, (unsigned long long)Fmax,
+      (unsigned long long)noise_mode, (unsigned long long)(uintptr_t)ids, (unsigned long long)(uintptr_t)lens,
+      (unsigned long long)(uintptr_t)ref_s, (unsigned long long)(uintptr_t)speed, (unsigned long long)(uintptr_t)forced_dur,
+      (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
+      (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
+      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion};
+  kk_model::GraphEntry* ge = nullptr;
+  for (auto& g : m->graphs)
+    if (g.key == key) ge = &g;
+  if (!ge) {
+    if (m->graphs.size() >= 16) {  // drop the oldest entry
+      if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
+      if (m->graphs.front().graph) (void)hipGraphDestroy(m->graphs.front().graph);
+      m->graphs.erase(m->graphs.begin());
+    }
+    m->graphs.emplace_back();
+    ge = &m->graphs.back();
+    ge->key = key;
+  }
+  if (ge->seen == 0) {  // first sight of this argument tuple: run eagerly (one-time attribute calls must not land in a capture)
+    ge->seen = 1;
+    return eager(stream);
+  }
+  if (!m->seed_dev && hipMalloc((void**)&m->seed_dev, 8) != hipSuccess) return kk_fail("kk_forward: hipMalloc(seed) failed");
+  if (ge->seen == 1) {
+    // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured); nothing runs
+    // during capture, and the instantiated graph is launched on the caller's stream
+    if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
+      return kk_fail("kk_forward: hipStreamCreate failed");
+    if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+      return kk_fail("kk_forward: hipStreamBeginCapture failed");
+    m->capturing = true;
+    const int rc = eager((void*)m->cap_stream);
+    m->capturing = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+    if (rc != 0) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    if (e != hipSuccess || !g) return kk_fail("kk_forward: hipStreamEndCapture failed");
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGraphDestroy(g);
+      return kk_fail("kk_forward: hipGraphInstantiate failed");
+    }
+    ge->graph = g;
+    ge->exec = ex;
+    ge->seen = 2;
+  }
+  // the seed is the one by-value argument that changes between replays: it travels through device memory
+  KK_TRY(kk_launch_set_u64(m->seed_dev, seed, st));
+  if (hipGraphLaunch(ge->exec, st) != hipSuccess) return kk_fail("kk_forward: hipGraphLaunch failed");
+  return 0;
+}
+
+extern "C" int kk_set_graph_mode(kk_model* m, int on) {
+  if (!m) return kk_fail("kk_set_graph_mode: null model");
+  m->graph_mode = on != 0;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1474,7 +1557,7 @@ extern "C" int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int l
                                        const void* res, int ldr, float scale, void* out, int ldo, float* stat_part, int* stat_ntiles_out) {
   KKMfmaArgs g;
   memset(&g, 0, sizeof g);
-  g.x = (const bf16_t*)x; g.xbs = (long long)L_rows * ldx; g.ldx = ldx; g.w = (const bf16_t*)w_bf16; g.CinP = CinP; g.CoutP = CoutP; g.bias = bias;
+  g.x = (const bf16_t*)x; g.xbs = (long long)L_rows * ldx; g.ldx = ldx; g.w = (const bf16_t*)w_bf16; g.CinP = CinP; g.Cin = Cin; g.CoutP = CoutP; g.bias = bias;
   g.out = out; g.obs = (long long)L_rows * ldo; g.ldo = ldo; g.res = res; g.rbs = (long long)L_rows * ldr; g.ldr = ldr;
   g.Cout = Cout; g.Kw = Kw; g.mode = KK_CONV; g.stride = 1; g.pad = pad; g.dil = dil; g.Q = L_rows; g.Lo_rows = L_rows;
   g.lin = KKLen{len, len ? 1 : 0, len ? 0 : L_rows};

@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256) void source_sample_kernel(KKSourceArgs a, floa
 #pragma unroll
     for (int h = 0; h < 9; ++h) nz[h] = np_[h];
   } else if (a.noise_mode == 2) {
+    const uint64_t seed = a.seed_dev ? *a.seed_dev : a.seed;
     const uint64_t ctr = (uint64_t)b * (uint64_t)a.Nmax + (uint64_t)n;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       uint32_t r[4];
-      philox4(a.seed, ctr, (uint32_t)g, r);
+      philox4(seed, ctr, (uint32_t)g, r);
       box_muller(r[0], r[1], nz[4 * g], nz[4 * g + 1]);
       box_muller(r[2], r[3], nz[4 * g + 2], nz[4 * g + 3]);
     }

@@ -56,6 +56,8 @@ class KokoroEngine:
         with torch.cuda.device(self.device):
             check(self.lib.kk_finalize(self._h, self._stream()), "kk_finalize")
         self._ws = None
+        self._graph = False
+        self._graph_bufs = {}
         self.upsample = int(np.prod(cfg["istftnet"]["upsample_rates"])) * cfg["istftnet"]["gen_istft_hop_size"] * 2  # samples / frame
 
     def _load(self, name: str, arr) -> None:
@@ -127,9 +129,19 @@ class KokoroEngine:
         B, Tmax = ids.shape
         self._last_B = B
         ws = self.workspace(B, Tmax, Fmax)
-        wav = out if out is not None else torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
-        pred = torch.empty((B, Tmax), dtype=torch.int32, device=self.device)
-        nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
+        if self._graph:
+            # graph replay is keyed on every pointer: the outputs live in buffers that persist across calls
+            key = (B, Tmax, Fmax)
+            if key not in self._graph_bufs:
+                self._graph_bufs[key] = (torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device),
+                                         torch.empty((B, Tmax), dtype=torch.int32, device=self.device),
+                                         torch.empty((B,), dtype=torch.int32, device=self.device))
+            gw, pred, nfr = self._graph_bufs[key]
+            wav = out if out is not None else gw
+        else:
+            wav = out if out is not None else torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
+            pred = torch.empty((B, Tmax), dtype=torch.int32, device=self.device)
+            nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         check(
             self.lib.kk_forward(
@@ -139,6 +151,12 @@ class KokoroEngine:
             "kk_forward",
         )
         return wav, pred, nfr
+
+    def set_graph_mode(self, on: bool = True) -> None:
+        """kk_set_graph_mode: repeated forward() calls with the same tensors become one hipGraphLaunch.  The returned
+        wav / pred_dur / nframes are then views of buffers that the next call with the same shapes overwrites."""
+        check(self.lib.kk_set_graph_mode(self._h, 1 if on else 0), "kk_set_graph_mode")
+        self._graph = bool(on)
 
     def forward_text(self, ids, lens, ref_s, speed):
         B, Tmax = ids.shape

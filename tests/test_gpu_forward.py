@@ -180,6 +180,68 @@ def test_tiny_batch_invariance_bitexact():
         np.testing.assert_array_equal(w1.cpu().numpy()[0], wav[b])
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_graph_replay_equals_eager_bitexact(dtype):
+    """kk_set_graph_mode: call 1 runs eagerly, call 2 is captured, calls 3+ replay the hipGraph.  Same seed -> the same bits as
+    the eager forward; a new seed reaches the replayed source kernel through device memory."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(31)
+    utts = [rng.integers(1, 178, n).tolist() for n in (12, 7, 9)]
+    eng = _engine(cfg, w, dtype)
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 3), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(3, device=dev)
+    e5 = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=5)]
+    e6 = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=6)]
+    torch.cuda.synchronize()
+    assert not torch.equal(e5[0], e6[0])  # the noise matters
+    eng.set_graph_mode(True)
+    for k, (seed, ref) in enumerate([(5, e5), (5, e5), (5, e5), (6, e6), (5, e5)]):  # eager, capture, replay, replay, replay
+        wav, pred, nfr = eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=seed)
+        torch.cuda.synchronize()
+        assert torch.equal(wav, ref[0]), (k, seed)
+        assert torch.equal(pred, ref[1]) and torch.equal(nfr, ref[2])
+    # other shapes get their own graph; the first one is still cached afterwards
+    i1, l1, T1 = eng.pack_ids(utts[:1])
+    for _ in range(3):
+        w1, _, _ = eng.forward(i1, l1, ref_s[:1].contiguous(), sp[:1].contiguous(), 110, noise_mode=_lib.NOISE_PHILOX, seed=5)
+    wav, _, _ = eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=6)
+    torch.cuda.synchronize()
+    assert torch.equal(wav, e6[0])
+    eng.set_graph_mode(False)
+
+
+@pytest.mark.parametrize("dtype,flags", [("float32", 0), ("bfloat16", 0), ("bfloat16", 2), ("bfloat16", 1)])
+def test_result_does_not_depend_on_workspace_contents(dtype, flags):
+    """Every byte the forward reads it has written first (or it is masked): a workspace full of 0xFF (NaN patterns in
+    fp32 and bf16) gives the same bits as a zeroed one.  Guards the pad channels / pad rows of the MFMA path."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(32)
+    utts = [rng.integers(1, 178, n).tolist() for n in (12, 7, 9)]
+    eng = _engine(cfg, w, dtype)
+    eng.lib.kk_debug_force_generic(eng._h, flags)
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 3), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(3, device=dev)
+    outs = []
+    for fill in (0, 255, 0x7F):
+        eng.workspace(3, Tmax, 110).fill_(fill)
+        wav, pred, nfr = eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=5)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(wav).all()), fill
+        outs.append((wav.clone(), pred.clone(), nfr.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
 def test_text_audio_split_equals_fused():
     from mlx_audio_amd import _lib
 
