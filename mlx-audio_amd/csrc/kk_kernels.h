@@ -74,6 +74,8 @@ struct KKStatsArgs {
 };
 size_t kk_stats_partial_floats(int B, int C, int Lmax, int rows_per_chunk);
 int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st);
+// adds ONE extra row of a bf16 tensor (row pointer per utterance = x + b*xbs) to tile 0 of the fused statistics partials
+int kk_launch_stat_add_row(const void* x, long long xbs, float* part, int ntiles, int C, int B, hipStream_t st);
 int kk_launch_norm_finalize(KKStatsArgs a, int B, hipStream_t st);  // fused partials -> mean/rstd (+ pa/pb)
 
 struct KKAdainArgs {

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void embedding_kernel(const int* ids, const fl
   kk_st(out + (long long)b * obs + (long long)t * ldo + c, v);
 }
 
-// one wave per token: lane o < nout computes sigmoid(x . W[o] + bias[o]); wave-sum; /speed; rint (half to even); >= 1
+// one wave per token: lane o < nout computes sigmoid(x . W[:, o] + bias[o]) (W transposed: [Cin][nout]); wave-sum; /speed; rint (half to even); >= 1
 template <typename T>
 __global__ __launch_bounds__(256) void duration_kernel(const T* x, long long xbs, int ldx, const float* W, const float* bias, int Cin,
                                                        int nout, const float* speed, int* dur, float* dur_f, int Tmax, KKLen len) {
@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void duration_kernel(const T* x, long long xbs
     const int o = o0 + lane;
     float sg = 0.f;
     if (o < nout) {
-      float acc = 0.f;
-      const float* wr = W + (long long)o * Cin;
-      for (int c = 0; c < Cin; ++c) acc = __builtin_fmaf(kk_ld(xr + c), wr[c], acc);
+      float acc = 0.f;  // same summation order as before (c ascending); W is [Cin][nout]
+      const float* wr = W + o;
+#pragma unroll 8
+      for (int c = 0; c < Cin; ++c) acc = __builtin_fmaf(kk_ld(xr + c), wr[(long long)c * nout], acc);
       acc += bias[o];
       sg = 1.0f / (1.0f + expf(-acc));
     }

@@ -610,7 +610,14 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   }
   m->pred_lstm = P.lstm("predictor.lstm", H + S, H / 2);
   m->shared_lstm = P.lstm("predictor.shared", H + S, H / 2);
-  m->dur_W = P.put_named("predictor.duration_proj.linear_layer.weight", (size_t)c.max_dur * H);
+  {  // stored transposed [H][max_dur]: the duration kernel's lanes (one per output bin) then read consecutive addresses
+    std::vector<float> wd, wt((size_t)c.max_dur * H);
+    if (P.vec("predictor.duration_proj.linear_layer.weight", (size_t)c.max_dur * H, wd)) {
+      for (int o = 0; o < c.max_dur; ++o)
+        for (int i = 0; i < H; ++i) wt[(size_t)i * c.max_dur + o] = wd[(size_t)o * H + i];
+      m->dur_W = P.put(wt);
+    }
+  }
   m->dur_b = P.put_named("predictor.duration_proj.linear_layer.bias", c.max_dur);
   for (int which = 0; which < 2; ++which) {
     const std::string nm = which == 0 ? "predictor.F0" : "predictor.N";
@@ -1319,6 +1326,8 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
       on.stride = sf0;
       on.pad = (sf0 + 1) / 2;
     }
+    const bool fuse_ok = c.adt == KK_BF16 && c.fz_part && !m->no_fusion && !m->force_generic;
+    bool xsrc_stats = false, xi_stats = false;
     const ConvW& nrows = m->noise_conv_rows[i];
     if (!last && nrows.mfma && c.adt == KK_BF16 && !m->force_generic && har.ld == 64 && on.stride <= 16 && nrows.Cin == on.stride * har.ld) {
       // stride-1 form over groups of `stride` rows (see Packer::strided_rows): valid groups = ceil(len / stride) = lst + 1
@@ -1329,11 +1338,15 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
       og.pad = m->noise_rows_pad[i];
       og.alg_taps_cin = (double)m->noise_conv[i].Kw * m->noise_conv[i].Cin;
       const KKLen lg = {lst.len, lst.mul, lst.add + 1};
+      og.want_stats = xsrc_stats = fuse_ok && c.can_mfma(nrows, hg, xsrc, og);
       KK_TRY(c.conv(nrows, hg, lg, xsrc, lst, Lst, og));
     } else {
+      on.want_stats = xsrc_stats = fuse_ok && c.can_mfma(m->noise_conv[i], har, xsrc, on);
       KK_TRY(c.conv(m->noise_conv[i], har, lTf, xsrc, lst, Lst, on));
     }
-    KK_TRY(run_resblock1(c, m->noise_res[i], xsrc, xsrc, t1, t2, Lst, lst, style_d, m->Nd, nullptr, 1.f, 0));
+    // the instance-norm statistics of the tensors the resblocks start from come out of their producers' epilogues
+    if (xsrc_stats) KK_TRY(c.finalize(Cst, lst, nullptr, 0, c.st_mean, c.st_rstd, nullptr, nullptr));
+    KK_TRY(run_resblock1(c, m->noise_res[i], xsrc, xsrc, t1, t2, Lst, lst, style_d, m->Nd, nullptr, 1.f, 0, xsrc_stats));
     ConvOpt ou;
     ou.mode = KK_CONVT;
     ou.stride = cf.upsample_rates[i];
@@ -1342,7 +1355,9 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     const int Qt = kk_cdiv(Lcur * cf.upsample_rates[i], cf.upsample_rates[i]);
     if (!last) {
       ou.res = &xsrc;
+      ou.want_stats = xi_stats = fuse_ok && c.can_mfma(m->ups[i], cur, xi, ou);
       KK_TRY(c.conv(m->ups[i], cur, lcur, xi, lst, Qt, ou));
+      if (xi_stats) KK_TRY(c.finalize(Cst, lst, nullptr, 0, c.st_mean, c.st_rstd, nullptr, nullptr));
     } else {
       // zero left pad of one frame (istftnet.py:786-787, "ReflectionPad1d" = mx.pad) then + x_source: the transposed conv
       // writes one row further down with x_source (same offset) as its residual; row 0 is x_source[0] alone.
@@ -1350,11 +1365,16 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
         KK_TRY(kk_launch_copy_slice(xsrc.p, xsrc.bs, xsrc.ld, xi.p, xi.bs, xi.ld, 0, Cst, 1, KKLen{lenF, 1, 0}, B, xi.dtype, c.st));
       Buf xi1 = xi.row_offset(1), xs1 = xsrc.row_offset(1);
       ou.res = &xs1;
+      ou.want_stats = xi_stats = fuse_ok && c.can_mfma(m->ups[i], cur, xi1, ou);
       KK_TRY(c.conv(m->ups[i], cur, lcur, xi1, lTfm1, Qt, ou));
+      if (xi_stats) {  // rows 1.. come from the conv's epilogue, row 0 (x_source[0], copied above) is added to tile 0
+        if (!c.dry) KK_TRY(kk_launch_stat_add_row(xi.p, xi.bs, c.fz_part, c.last_ntiles, Cst, B, c.st));
+        KK_TRY(c.finalize(Cst, lst, nullptr, 0, c.st_mean, c.st_rstd, nullptr, nullptr));
+      }
     }
     KK_TRY(c.dbg(i == 0 ? "gen_pre_res0" : "gen_pre_res1", xi, Cst));
     for (int j = 0; j < nk; ++j)
-      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0, j > 0));
+      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0, j > 0 || xi_stats));
     KK_TRY(c.dbg(i == 0 ? "gen_stage0" : "gen_stage1", accb, Cst));
     cur = accb;
     lcur = lst;

@@ -336,6 +336,24 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void stat_add_row_kernel(const bf16_t* x, long long xbs, float* part, int ntiles, int C) {
+  const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float v = (float)x[(long long)b * xbs + c];
+  float* p = part + ((long long)b * ntiles * 2) * C + c;
+  p[0] += v;
+  p[C] = __builtin_fmaf(v, v, p[C]);
+}
+}  // namespace
+
+int kk_launch_stat_add_row(const void* x, long long xbs, float* part, int ntiles, int C, int B, hipStream_t st) {
+  if (B <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(stat_add_row_kernel, dim3(B, kk_cdiv(C, 256)), dim3(256), 0, st, (const bf16_t*)x, xbs, part, ntiles, C);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
 int kk_launch_norm_finalize(KKStatsArgs a, int B, hipStream_t st) {
   if (B <= 0 || a.C <= 0) return 0;
   const int cover = a.pa ? (a.Cp > a.C ? a.Cp : a.C) : a.C;
