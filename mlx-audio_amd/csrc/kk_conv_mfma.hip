@@ -52,6 +52,7 @@ extern "C" int kk_debug_mfma_trace(unsigned long long* out8, int reset) {
 #endif
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -345,12 +346,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int nc = n < a.Cout ? n : 0;  // clamped for the unconditional loads
   const int lo_hi = a.Lo_rows - 1;
   constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
-  float bias8[8];
+  v2f bias2[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bias8[k] = a.bias ? a.bias[n0 + (tid & 15) * 8 + k] : 0.f;  // bias has CoutP entries
-  float st_s[8], st_q[8];  // column sums / sums of squares of the values this thread stores
+  for (int k = 0; k < 4; ++k)  // bias has CoutP entries
+    bias2[k] = a.bias ? v2f{a.bias[n0 + (tid & 15) * 8 + 2 * k], a.bias[n0 + (tid & 15) * 8 + 2 * k + 1]} : v2f{0.f, 0.f};
+  const v2f scale2 = {a.scale, a.scale}, act_slope2 = {a.act_slope, a.act_slope};
+  v2f st_s[4], st_q[4];  // column sums / sums of squares of the values this thread stores (pairs of adjacent columns)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) st_s[k] = st_q[k] = 0.f;
+  for (int k = 0; k < 4; ++k) st_s[k] = st_q[k] = v2f{0.f, 0.f};
 
   constexpr int RPP = G::RPP, NPASS = BM / RPP, TASKS = RPP * 16 / 256, TG = TASKS / 2;  // 8 or 6 row tasks per thread and pass
   // bf16 residual rows of the WHOLE tile are requested up front (xreg / w registers are dead by now): one exposed HBM
@@ -418,77 +421,90 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int i = 0; i < TG; ++i) {
+        // the element-wise chain runs on float PAIRS (v_pk_add/mul/fma_f32: two lanes of fp32 per instruction, same IEEE
+        // results as the scalar form); bf16 <-> fp32 widening is a shift / mask on the packed word
         const int row = ((half * TG + i) * 256 + tid) >> 4;
-        float v[8];
+        v2f v[4];
         if (tile_live) {
           const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
           const float4 c1 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8 + 4);
-          v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+          v[0] = v2f{c0.x, c0.y}; v[1] = v2f{c0.z, c0.w}; v[2] = v2f{c1.x, c1.y}; v[3] = v2f{c1.z, c1.w};
         } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = 0.f;
+          for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+        for (int k = 0; k < 4; ++k) v[k] += bias2[k];
         if (a.act == KK_ACT_LRELU) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.act_slope;
+          for (int k = 0; k < 4; ++k) {
+            const v2f m = v[k] * act_slope2;
+            v[k].x = v[k].x > 0.f ? v[k].x : m.x;
+            v[k].y = v[k].y > 0.f ? v[k].y : m.y;
+          }
         } else if (a.act == KK_ACT_GELU) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = gelu_exact(v[k]);
+          for (int k = 0; k < 4; ++k) {
+            v[k].x = gelu_exact(v[k].x);
+            v[k].y = gelu_exact(v[k].y);
+          }
         }
         if (rb) {
           if (sizeof(TO) == 2) {
-            U16 t;
-            t.u = rres[i][0];
+            const unsigned w4[4] = {rres[i][0].x, rres[i][0].y, rres[i][0].z, rres[i][0].w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+            for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
           } else {
             U32x8 t;
             t.u[0] = rres[i][0];
             t.u[1] = rres[i][VEC - 1];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+            for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
           }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= a.scale;
+        for (int k = 0; k < 4; ++k) v[k] *= scale2;
         if (a.accumulate) {
           if (sizeof(TO) == 2) {
-            U16 t;
-            t.u = rold[i][0];
+            const unsigned w4[4] = {rold[i][0].x, rold[i][0].y, rold[i][0].z, rold[i][0].w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t.h[k];
+            for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
           } else {
             U32x8 t;
             t.u[0] = rold[i][0];
             t.u[1] = rold[i][VEC - 1];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += t.f[k];
+            for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
           }
         }
-        if (!live[i]) {
+        if (sizeof(TO) == 2) {
+          const unsigned lm = live[i] ? 0xFFFFFFFFu : 0u;  // rows past the utterance are stored as exact zeros
+          unsigned w4[4];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = 0.f;
-        }
-        if (wr_ok[i]) {
-          TO* dst = ob + (long long)opv[i] * a.ldo + n;
-          if (sizeof(TO) == 2) {
-            U16 t;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t.h[k] = (bf16_t)v[k];
-            *(uint4*)dst = t.u;
+          for (int k = 0; k < 4; ++k) {
+            const bf16x2 pk = {(bf16_t)v[k].x, (bf16_t)v[k].y};
+            w4[k] = __builtin_bit_cast(unsigned, pk) & lm;
+          }
+          if (wr_ok[i]) {
+            *(uint4*)(ob + (long long)opv[i] * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
             if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
 #pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                const float r = (float)t.h[k];
+              for (int k = 0; k < 4; ++k) {
+                const v2f r = {__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
                 st_s[k] += r;
-                st_q[k] = __builtin_fmaf(r, r, st_q[k]);
+                st_q[k] = __builtin_elementwise_fma(r, r, st_q[k]);
               }
             }
-          } else {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        } else {
+          if (!live[i]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
+          }
+          if (wr_ok[i]) {
+            float* dst = (float*)(ob + (long long)opv[i] * a.ldo + n);
+            *(float4*)dst = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+            *(float4*)(dst + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
           }
         }
       }
@@ -502,18 +518,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // then over the 4 waves through LDS; one deterministic partial per (utterance, tile, column)
     __syncthreads();  // every wave is done reading the Cs tile
     float* red = (float*)smem;  // [4 waves][2][128]
+    float ss[8], sq[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ss[2 * k] = st_s[k].x; ss[2 * k + 1] = st_s[k].y;
+      sq[2 * k] = st_q[k].x; sq[2 * k + 1] = st_q[k].y;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      st_s[k] += __shfl_xor(st_s[k], 16);
-      st_s[k] += __shfl_xor(st_s[k], 32);
-      st_q[k] += __shfl_xor(st_q[k], 16);
-      st_q[k] += __shfl_xor(st_q[k], 32);
+      ss[k] += __shfl_xor(ss[k], 16);
+      ss[k] += __shfl_xor(ss[k], 32);
+      sq[k] += __shfl_xor(sq[k], 16);
+      sq[k] += __shfl_xor(sq[k], 32);
     }
     if (lane < 16) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        red[(wave * 2 + 0) * 128 + lane * 8 + k] = st_s[k];
-        red[(wave * 2 + 1) * 128 + lane * 8 + k] = st_q[k];
+        red[(wave * 2 + 0) * 128 + lane * 8 + k] = ss[k];
+        red[(wave * 2 + 1) * 128 + lane * 8 + k] = sq[k];
       }
     }
     __syncthreads();
