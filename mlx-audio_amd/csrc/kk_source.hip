@@ -10,6 +10,8 @@
 // phase accumulator reaches 1e5..1e6 rad, where one float32 ulp is 0.01..0.1 rad): sequential
 // cumsum, (cumsum*2)*pi*300, the un-clamped linear interpolation with its wrap to the LAST sample
 // for the first 150 outputs (interpolate.py:88-106), un-fused multiply/add in the blend.
+#include <stdlib.h>
+
 #include "kk_common.h"
 #include "kk_kernels.h"
 
@@ -204,10 +206,13 @@ constexpr int IH_NF = IH_FR + 3;
 
 template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
-                                                         long long wbs, Tables tb) {
+                                                         long long wbs, int stage_off, Tables tb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ism[];
-  float* ys = (float*)ism;                          // [255][21]
-  unsigned char* tile = ism + IH_NF * 21 * 4;       // [255][ldx] input tile, later the output staging
+  // LDS: [ input tile [255][ldx]  ALIASED WITH  ys [255][21] fp32 ] [ stage [252][5] fp32 ] -- the tile is dead once every
+  // thread holds its frame's 22 spectrum values in registers (barrier), so 26.5 KB (bf16 input) per workgroup instead of 34 KB:
+  // 6 workgroups per CU instead of 4 to hide the tile-load latency
+  float* ys = (float*)ism;   // [255][21]
+  unsigned char* tile = ism;  // [255][ldx]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int Tf = len_frames ? len_frames[b] : Tfmax;
   const int g0 = blockIdx.x * IH_FR;  // first hop-block of this workgroup
@@ -231,12 +236,14 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
   }
   __syncthreads();
   // ---- phase 1: windowed inverse real DFT of frames f0 .. f0+254
-  for (int i = tid; i < IH_NF; i += 256) {
+  {
+    const int i = tid;  // IH_NF = 255 frames <= 256 threads
     const int f = f0 + i;
     float* yo = ys + i * 21;
-    if (f >= 0 && f < Tf) {
+    const bool fv = i < IH_NF && f >= 0 && f < Tf;
+    float re[11], im[11];
+    if (fv) {
       const T* xr = (const T*)(tile + (long long)i * row_bytes);
-      float re[11], im[11];
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
         const float lm = kk_ld(xr + k), pr = kk_ld(xr + 11 + k);
@@ -247,6 +254,9 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
         re[k] = mag * c;
         im[k] = mag * s;
       }
+    }
+    __syncthreads();  // every thread has read its row: ys may now overwrite the tile
+    if (fv) {
       // x[o] = (re0 + (-1)^o re10 + 2 (C[o] - S[o])) / 20,  x[20-o] = (.. + 2 (C[o] + S[o])) / 20  with
       //   C[o] = sum_k re[k] cos(2 pi k o / 20),  S[o] = sum_k im[k] sin(2 pi k o / 20),  k = 1..9.
       // Even / odd k split: cos(2 pi k (10-o)/20) = (-1)^k cos(..o..), sin(2 pi k (10-o)/20) = -(-1)^k sin(..o..), so
@@ -279,14 +289,14 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
           if (p < 10) yo[20 - p] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - p];
         }
       }
-    } else {
+    } else if (i < IH_NF) {
 #pragma unroll
       for (int o = 0; o < 20; ++o) yo[o] = 0.f;
     }
   }
   __syncthreads();
   // ---- phase 2: overlap-add in ascending frame order, normalise by the window sum, trim 10 | 10
-  float* stage = (float*)tile;  // [252][5]
+  float* stage = (float*)(ism + stage_off);  // [252][5]
   const int g = g0 + tid;
   const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
 #pragma unroll
@@ -325,6 +335,107 @@ __global__ __launch_bounds__(256) void istft_head_kernel(const T* x, long long x
   }
 }
 
+// ------------------------------------------------------------------ iSTFT head, wave-local form (no LDS, no barriers)
+// Lane l of a wave owns frame f = gw0 - 3 + l; the <= 4 frames that overlap hop block g = f live in lanes l-3 .. l, so the
+// overlap-add is 15 __shfl_up and lanes 3..63 each produce the 5 samples of their hop block (61 hop blocks per wave; the 3
+// halo frames per wave are recomputed, 5 %).  Occupancy is then bounded by VGPRs alone (8 waves per SIMD), which is what this
+// transcendental-bound kernel needs to hide its input latency.  Same arithmetic and the same ascending-frame summation order
+// as the tiled kernel above (the reference's scatter-add order, utils.py:138-147).
+constexpr int IW_HB = 61;  // hop blocks per wave
+
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void istft_head_wave_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
+                                                              long long wbs, Tables tb) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Tf = len_frames ? len_frames[b] : Tfmax;
+  const int g0 = (blockIdx.x * 4 + wv) * IW_HB;  // first hop block of this wave
+  if (g0 >= Tfmax + 3) return;                   // whole wave (no barriers in this kernel)
+  const int f = g0 - 3 + lane;
+  const bool fv = f >= 0 && f < Tf;
+  float y[20];
+  if (fv) {
+    const T* xr = x + (long long)b * xbs + (long long)f * ldx;
+    float in[22];
+    if (sizeof(T) == 2 && (ldx & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)xbs * 2)) & 15) == 0) {
+      // 22 bf16 = 44 bytes: three 16-byte loads (the row pitch is >= 24 elements)
+      union { uint4 u[3]; bf16_t h[24]; } r;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) r.u[q] = *((const uint4*)xr + q);
+#pragma unroll
+      for (int k = 0; k < 22; ++k) in[k] = (float)r.h[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 22; ++k) in[k] = kk_ld(xr + k);
+    }
+    float re[11], im[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float lm = in[k], pr = in[11 + k];
+      const float mag = FAST ? __expf(lm) : expf(lm);
+      const float ph = FAST ? __sinf(pr) : sinf(pr);
+      float s, c;
+      if (FAST) __sincosf(ph, &s, &c); else sincosf(ph, &s, &c);
+      re[k] = mag * c;
+      im[k] = mag * s;
+    }
+#pragma unroll
+    for (int o = 0; o <= 5; ++o) {
+      float Ce = 0.f, Co = 0.f, Se = 0.f, So = 0.f;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) {
+        const int m = (k * o) % 20;
+        if (k & 1) {
+          Co = __builtin_fmaf(re[k], tb.cs[m], Co);
+          So = __builtin_fmaf(im[k], tb.sn[m], So);
+        } else {
+          Ce = __builtin_fmaf(re[k], tb.cs[m], Ce);
+          Se = __builtin_fmaf(im[k], tb.sn[m], Se);
+        }
+      }
+      {
+        const float C = Ce + Co, S = Se + So;
+        const float dc = re[0] + ((o & 1) ? -re[10] : re[10]);
+        y[o] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[o];
+        if (o > 0) y[20 - o] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - o];
+      }
+      if (o < 5) {
+        const int p = 10 - o;
+        const float C = Ce - Co, S = So - Se;
+        const float dc = re[0] + ((p & 1) ? -re[10] : re[10]);
+        y[p] = (dc + 2.0f * (C - S)) * 0.05f * tb.hann_per[p];
+        if (p < 10) y[20 - p] = (dc + 2.0f * (C + S)) * 0.05f * tb.hann_per[20 - p];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < 20; ++o) y[o] = 0.f;
+  }
+  // overlap-add: sample 5 g + r - 10 = sum over j = 3..0 of frame (g - j)'s sample 5 j + r, ascending frame order
+  const int g = f;
+  const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
+  const long long ntot = 5LL * (Tfmax - 1);
+  float* wb = wav + (long long)b * wbs;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    float acc = 0.f, ws = 0.f;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const float v = j ? __shfl_up(y[5 * j + r], j) : y[r];  // lanes < j read their own value: they produce no output
+      const int fj = g - j;
+      if (fj >= 0 && fj < Tf) {
+        acc += v;
+        ws += tb.hann_per[5 * j + r];
+      }
+    }
+    const long long n = 5LL * g + r - 10;
+    if (lane >= 3 && g < g0 + IW_HB && n >= 0 && n < ntot) {
+      float v = 0.f;
+      if (n < nout) v = ws != 0.f ? (FAST ? acc * __builtin_amdgcn_rcpf(ws) : acc / ws) : acc;
+      wb[n] = v;
+    }
+  }
+}
+
 const Tables g_tables = make_tables();
 
 }  // namespace
@@ -357,21 +468,37 @@ int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_f
                          int dtype, int fast, hipStream_t st) {
   if (B <= 0 || Tfmax <= 0) return 0;
   if (ldx < 22 || ldx > 64) return kk_fail("istft_head: input pitch must be in [22, 64]");
+  static int tiled = -1;
+  if (tiled < 0) tiled = getenv("KK_ISTFT_TILED") ? 1 : 0;  // A/B switch: the LDS-tiled kernel
+  if (!tiled) {
+    dim3 gw(kk_cdiv(Tfmax + 3, 4 * IW_HB), B);
+    if (dtype == KK_F32) {
+      if (fast) hipLaunchKernelGGL((istft_head_wave_kernel<float, true>), gw, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      else hipLaunchKernelGGL((istft_head_wave_kernel<float, false>), gw, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    } else {
+      if (fast) hipLaunchKernelGGL((istft_head_wave_kernel<bf16_t, true>), gw, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      else hipLaunchKernelGGL((istft_head_wave_kernel<bf16_t, false>), gw, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    }
+    KK_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid(kk_cdiv(Tfmax + 3, IH_FR), B);
   const size_t esz = dtype == KK_F32 ? 4 : 2;
-  size_t tile = (size_t)IH_NF * ldx * esz;
-  if (tile < (size_t)IH_FR * 5 * 4) tile = (size_t)IH_FR * 5 * 4;
-  const size_t lds = (size_t)IH_NF * 21 * 4 + ((tile + 15) & ~(size_t)15);
+  size_t front = (size_t)IH_NF * ldx * esz;  // input tile, aliased with ys
+  if (front < (size_t)IH_NF * 21 * 4) front = (size_t)IH_NF * 21 * 4;
+  front = (front + 15) & ~(size_t)15;
+  const int soff = (int)front;
+  const size_t lds = front + (size_t)IH_FR * 5 * 4;
   if (dtype == KK_F32) {
     if (fast)
-      hipLaunchKernelGGL((istft_head_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, soff, g_tables);
     else
-      hipLaunchKernelGGL((istft_head_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, soff, g_tables);
   } else {
     if (fast)
-      hipLaunchKernelGGL((istft_head_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, soff, g_tables);
     else
-      hipLaunchKernelGGL((istft_head_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+      hipLaunchKernelGGL((istft_head_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, soff, g_tables);
   }
   KK_CHECK_LAUNCH();
   return 0;
