@@ -155,6 +155,58 @@ def test_tiny_ragged_batch_matches_oracle():
         assert worst[k] < 2e-4, (k, worst[k])
 
 
+def test_max_context_and_single_phoneme_match_oracle():
+    """The reference caps the context at 512 tokens (kokoro.py:131-134: 510 phonemes + BOS/EOS) and has no lower bound: one
+    batch holds the longest legal utterance and a single phoneme (T = 3).  Exercises the 512-row position table, 16 key
+    tiles of attention, the 512-thread alignment scan and tiles that are almost empty."""
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(40)
+    utts = [rng.integers(1, 178, 510).tolist(), rng.integers(1, 178, 1).tolist()]
+    r = _run_pair(cfg, w, utts, [1.0, 1.0], seed=2, forced=2, tag="maxctx")
+    assert r["lens"] == [512, 3] and r["Fs"] == [1024, 6]
+    for b, a in enumerate(r["o_audio"]):
+        n = a.shape[0]
+        assert r["nfr"][b] == r["Fs"][b]
+        e = err_stats(r["wav"][b, :n], a)
+        report(f"maxctx/wav/b{b}", **e)
+        assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+        assert np.all(r["wav"][b, n:] == 0)
+    for k in ("bert_dur", "d", "t_en", "en", "asr", "F0_pred", "N_pred", "dec_out"):
+        assert r["stage_worst"][k] < 2e-4, (k, r["stage_worst"][k])
+
+
+def test_frames_past_fmax_are_dropped_and_reported():
+    """kk_forward realises the predicted durations on the device; an utterance that needs more than Fmax frames is cut at
+    Fmax (nframes reports what was produced, samples past 600 * nframes are zero, nothing overruns the buffers)."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(41)
+    utts = [rng.integers(1, 178, n).tolist() for n in (20, 6)]
+    eng = _engine(cfg, w)
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 2), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(2, device=dev)
+    _, pred, nfull = eng.forward(ids, lens, ref_s, sp, 400, noise_mode=_lib.NOISE_ZERO)
+    torch.cuda.synchronize()
+    need = pred.sum(dim=1).cpu().numpy()
+    assert np.array_equal(nfull.cpu().numpy(), need) and need[0] > need[1] > 0
+    Fcut = int(need[1]) + 3  # the short utterance fits, the long one does not
+    assert Fcut < need[0]
+    guard = torch.full((2 * 600 * Fcut + 64,), 7.0, device=dev)
+    wav, pred2, nfr = eng.forward(ids, lens, ref_s, sp, Fcut, noise_mode=_lib.NOISE_ZERO, out=guard[: 2 * 600 * Fcut].view(2, 600 * Fcut))
+    torch.cuda.synchronize()
+    assert torch.equal(pred2, pred)  # the predictor does not depend on Fmax
+    assert nfr.cpu().numpy().tolist() == [Fcut, int(need[1])]
+    wav = wav.cpu().numpy()
+    assert np.isfinite(wav).all() and np.abs(wav[0]).max() > 0
+    assert np.all(wav[1, 600 * int(need[1]):] == 0)
+    assert bool((guard[2 * 600 * Fcut:] == 7.0).all())  # nothing written past the caller's buffer
+
+
 def test_tiny_batch_invariance_bitexact():
     """An utterance gives the same bits alone and inside a ragged batch (B independent B=1 calls, kokoro.py:135-136)."""
     from mlx_audio_amd import _lib
