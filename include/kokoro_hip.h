@@ -161,8 +161,12 @@ int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channel
 int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
 int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
 void kk_debug_clear(kk_model* m);
-void kk_debug_set_mfma3(int on); /* process-wide: route long bf16 convs to the experimental persistent 256-row kernel */
-void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion */
+/* variant 4 of the bf16 conv kernel reads its weights in MFMA fragment order: kk_op_pack_w_frag re-lays a [Kw][CoutP][CinP] bf16
+ * pack out (device to device, same size); kk_debug_set_op_wfrag(wf) makes the kk_op_conv1d_bf16* calls that follow run variant 4
+ * with that pack (NULL = back to the LDS-staged kernel).  The model packs both layouts in kk_finalize. */
+int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP);
+void kk_debug_set_op_wfrag(const void* w_frag);
+void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4 */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention

@@ -56,7 +56,8 @@ SIGNATURES = {
     "kk_debug_override": (_i, [_vp, C.c_char_p, _vp]),
     "kk_debug_clear": (None, [_vp]),
     "kk_debug_force_generic": (None, [_vp, _i]),
-    "kk_debug_set_mfma3": (None, [_i]),
+    "kk_op_pack_w_frag": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kk_debug_set_op_wfrag": (None, [_vp]),
     "kk_set_graph_mode": (_i, [_vp, _i]),
     "kk_profile_begin": (_i, [_vp, _i]),
     "kk_profile_end": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1,3 +1,9 @@
+// Variant 4 of the bf16 MFMA implicit-GEMM convolution (see kk_conv_mfma.hip for the base design): the weight (B) fragments
+// do NOT go through LDS.  W is packed in FRAGMENT ORDER at load time (kk_mfma4_pack_index), so a wave fetches the 1 KiB
+// fragment of its 32 output channels x 16 k for one k-step as ONE fully coalesced global_load_dwordx4, straight into the MFMA
+// operand registers, one (tap, slab) iteration ahead.  That removes the W double buffer (LDS 73 -> 48 KB), the ds_write of W,
+// 8 of the 20 ds_read_b128 per wave and iteration, and the barrier per tap: waves synchronise only when the X slab changes.
+//
 // bf16 MFMA implicit-GEMM convolution for frames-major tensors (gfx950, v_mfma_f32_32x32x16_bf16).
 //
 //   out[b][q][n] = sum_t sum_ci  W[t][n][ci] * f(X[b][q + off_t][ci])       (stride 1, any dilation)
@@ -25,31 +31,8 @@
 #include "kk_common.h"
 #include "kk_kernels.h"
 
-#ifdef KK_MFMA_TRACE
-// phase timing of wave 0 of every workgroup (tools/bench_conv.py --trace; never compiled into the shipped library)
-__device__ unsigned long long kk_mfma_trace_acc[1024][8];  // spread over 1024 rows: same-address atomics would serialise
-#define TR_NOW() (__builtin_readcyclecounter())
-#define TR_ADD(slot, v) \
-  do { if (threadIdx.x == 0) atomicAdd(&kk_mfma_trace_acc[(blockIdx.x + 37 * blockIdx.z) & 1023][slot], (unsigned long long)(v)); } while (0)
-extern "C" int kk_debug_mfma_trace(unsigned long long* out8, int reset) {
-  static unsigned long long h[1024][8];
-  if (out8) {
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kk_mfma_trace_acc), sizeof(h)) != hipSuccess) return -1;
-    for (int k = 0; k < 8; ++k) out8[k] = 0;
-    for (int r = 0; r < 1024; ++r)
-      for (int k = 0; k < 8; ++k) out8[k] += h[r][k];
-  }
-  if (reset) {
-    for (int r = 0; r < 1024; ++r)
-      for (int k = 0; k < 8; ++k) h[r][k] = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(kk_mfma_trace_acc), h, sizeof(h)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#else
 #define TR_NOW() 0ull
 #define TR_ADD(slot, v) do { } while (0)
-#endif
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -61,14 +44,14 @@ constexpr int BN = 128, CK = 64;
 constexpr int XLD = CK + 8;   // elements per LDS row (144 B)
 constexpr int MAX_HALO = 50;  // (Kw-1)*dil of the largest resblock conv (k 11, dilation 5)
 constexpr int CLD = BN;       // fp32 epilogue tile pitch: 128 x 128 x 4 B = exactly 64 KiB
-constexpr int WS_BYTES = BN * XLD * 2;    // 18432 per buffer
+
 constexpr int PS_BYTES = 2 * 3 * CK * 4;  // double-buffered AdaIN parameter table of one slab (A, B, alpha)
 
 template <int BM>
 struct Geo {
   static constexpr int XROWS = BM + MAX_HALO;
   static constexpr int XS_BYTES = XROWS * XLD * 2;
-  static constexpr int MAIN_BYTES = XS_BYTES + 2 * WS_BYTES + PS_BYTES;
+  static constexpr int MAIN_BYTES = XS_BYTES + PS_BYTES;
   static constexpr int RPP = BM == 128 ? 128 : BM / 2;  // rows per epilogue pass (one wave row group for the tall tiles)
   static constexpr int EPI_BYTES = RPP * CLD * 4;
   static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
@@ -88,15 +71,13 @@ union U32x8 {
 
 // NRM: 0 = raw input, 1 = AdaIN + Snake while staging, 2 = AdaIN + LeakyReLU(nrm_slope; 1 = identity) while staging
 template <typename TO, int WM, int NRM>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma_kernel(KKMfmaArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma4_kernel(KKMfmaArgs a) {
   constexpr int BM = 2 * WM, MI = WM / 32;
   using G = Geo<BM>;
   constexpr int XREG = G::XREG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Xs = (bf16_t*)smem;
-  bf16_t* Ws0 = (bf16_t*)(smem + G::XS_BYTES);
-  bf16_t* Ws1 = (bf16_t*)(smem + G::XS_BYTES + WS_BYTES);
-  float* Ps = (float*)(smem + G::XS_BYTES + 2 * WS_BYTES);  // [2][3][64]
+  float* Ps = (float*)(smem + G::XS_BYTES);  // [2][3][64]
   float* Cs = (float*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -247,103 +228,85 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
       }
     };
-    // four named registers instead of an array: hipcc kept a `uint4 wreg[4]` captured by the lambdas in scratch memory
-    // (global load -> wait -> scratch store), which turned the prefetch into a synchronous copy
-    uint4 w0, w1, w2, w3;
-    auto load_w = [&](int it) __attribute__((always_inline)) {
+    // B fragments of one (tap, slab) iteration: [ni][ks], loaded from the fragment-order pack one iteration ahead.  Named
+    // scalars, not an array (hipcc put a lambda-captured register array in scratch once already).
+    uint4 q00, q01, q02, q03, q10, q11, q12, q13;
+    const int nb = blockIdx.y;
+    auto frag_ptr = [&](int it) __attribute__((always_inline)) -> const uint4* {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
-      const bf16_t* wt = a.w + ((long long)(widx0 + tap * wstep) * a.CoutP + n0) * a.CinP + chunk * CK + (long long)(tid >> 3) * a.CinP + (tid & 7) * 8;
-      const long long step = (long long)32 * a.CinP;  // 256 threads cover 32 rows of 8 chunks
-      w0 = *(const uint4*)(wt);
-      w1 = *(const uint4*)(wt + step);
-      w2 = *(const uint4*)(wt + 2 * step);
-      w3 = *(const uint4*)(wt + 3 * step);
-      asm volatile("" ::: "memory");
+      // pack order: [tap][n block][chunk][wc][ni][ks][lane] x 16 bytes
+      const long long blk = ((long long)(widx0 + tap * wstep) * (a.CoutP / BN) + nb) * nchunk + chunk;
+      return (const uint4*)a.wf + blk * 1024 + (wc * 2) * 4 * 64 + lane;
     };
-    auto store_w = [&](bf16_t* Ws) __attribute__((always_inline)) {
-      bf16_t* d = Ws + (tid >> 3) * XLD + (tid & 7) * 8;
-      *(uint4*)(d) = w0;
-      *(uint4*)(d + 32 * XLD) = w1;
-      *(uint4*)(d + 64 * XLD) = w2;
-      *(uint4*)(d + 96 * XLD) = w3;
-    };
-
     // ---- prologue
     load_x(0);
-    load_w(0);
+    {
+      const uint4* fp = frag_ptr(0);
+      q00 = fp[0 * 64]; q01 = fp[1 * 64]; q02 = fp[2 * 64]; q03 = fp[3 * 64];
+      q10 = fp[4 * 64]; q11 = fp[5 * 64]; q12 = fp[6 * 64]; q13 = fp[7 * 64];
+      asm volatile("" ::: "memory");
+    }
     store_p(0);
-    store_w(Ws0);
     __syncthreads();
     store_x(0);
     __syncthreads();
-    if (nit > 1) load_w(1);
-    const unsigned long long tr1 = TR_NOW();
-    (void)tr1;
-    TR_ADD(0, tr1 - tr0);  // prologue: first X slab + first W tile on chip
 
     const int arow = wr * WM + (lane & 31);  // + mi*32 + tap shift
-    const int brow = wc * 64 + (lane & 31);  // + ni*32
     const int kofs = 8 * (lane >> 5);
 
     for (int it = 0; it < nit; ++it) {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
-      const bf16_t* Ws = (it & 1) ? Ws1 : Ws0;
       const bool last_tap = tap == ntaps - 1;
       // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land
       if (tap == 0 && chunk + 1 < nchunk) load_x(chunk + 1);
+      // next iteration's fragments (the last iteration re-requests its own: no branch around the loads)
+      const uint4* fn = frag_ptr(it + 1 < nit ? it + 1 : it);
 
       const int shift = (off0 + tap * dstep) - min_off;  // row shift of this tap inside the X slab
       const bf16_t* xa = Xs + (arow + shift) * XLD + kofs;
-      const bf16_t* wb = Ws + brow * XLD + kofs;
-#pragma unroll
-      for (int ks = 0; ks < CK / 16; ++ks) {
-        const bf16x8 b0 = *(const bf16x8*)(wb + ks * 16);
-        const bf16x8 b1 = *(const bf16x8*)(wb + 32 * XLD + ks * 16);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const bf16x8 av = *(const bf16x8*)(xa + mi * 32 * XLD + ks * 16);
-          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[mi][0], 0, 0, 0);
-          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[mi][1], 0, 0, 0);
-        }
+#define KK_KSTEP(KS, B0, B1)                                                                                        \
+      {                                                                                                              \
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, B0), b1 = __builtin_bit_cast(bf16x8, B1);                     \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                          \
+          const bf16x8 av = *(const bf16x8*)(xa + mi * 32 * XLD + (KS) * 16);                                       \
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[mi][0], 0, 0, 0);                         \
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[mi][1], 0, 0, 0);                         \
+        }                                                                                                            \
+        B0 = fn[(KS) * 64];       /* the registers are free as soon as these MFMAs are issued */                   \
+        B1 = fn[(4 + (KS)) * 64];                                                                                   \
       }
-#ifndef KK_MFMA_NO_SGB
-      // prescribe the issue order: the fragments of k-step ks+1 are read from LDS WHILE the MFMAs of k-step ks run.  Left to
-      // itself hipcc issues all 4 k-steps' ds_reads first and the 24 MFMAs after them, and the waves of a CU then fall into
-      // lock step (everyone reads LDS, then everyone computes): measured 2860 cycles per iteration = LDS time + MFMA time.
+      KK_KSTEP(0, q00, q10)
+      KK_KSTEP(1, q01, q11)
+      KK_KSTEP(2, q02, q12)
+      KK_KSTEP(3, q03, q13)
+#undef KK_KSTEP
+      // issue order: the A fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run, and the two global
+      // loads that refill a k-step's B registers go out right behind that k-step's MFMAs (hipcc otherwise parks all eight at the
+      // end of the iteration, one barrier away from their first use)
       {
-        constexpr int NF = 2 + MI, NM = 2 * MI;
-        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);
 #pragma unroll
-        for (int ks = 0; ks < CK / 16 - 1; ++ks) {
+        for (int ks = 0; ks < CK / 16; ++ks) {
 #pragma unroll
-          for (int j = 0; j < NF; ++j) {
+          for (int j = 0; j < MI; ++j) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (ks < CK / 16 - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-          if (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
       }
-#endif
+      asm volatile("" ::: "memory");
       if (it + 1 < nit) {
-        const unsigned long long ta = TR_NOW();
-        store_w((it & 1) ? Ws0 : Ws1);  // buffer last read in iteration it-1; every wave has passed that barrier
         if (tap == 0 && chunk + 1 < nchunk) store_p(chunk + 1);  // parameter loads were issued with load_x above
-        const unsigned long long tb = TR_NOW();
-        tr_sw += tb - ta;
         if (last_tap) {
           __syncthreads();  // all waves are done with the X slab
           store_x(chunk + 1);
-          tr_sx += TR_NOW() - tb;
+          __syncthreads();
         }
-        __syncthreads();
-        if (it + 2 < nit) load_w(it + 2);
       }
     }
     __syncthreads();  // main-loop LDS is dead; the epilogue tile aliases it
-    TR_ADD(1, TR_NOW() - tr1);  // main loop
-    TR_ADD(2, tr_sw);           //   of which: waiting for + storing the prefetched W tile
-    TR_ADD(3, tr_sx);           //   of which: barrier + transform + store of the next X slab
   }
 
   // ---- epilogue: per 128 rows, accumulators -> fp32 LDS tile -> coalesced rows --------------------------------------
@@ -561,67 +524,59 @@ int launch_one(const KKMfmaArgs& a, int B, hipStream_t st) {
   using G = Geo<2 * WM>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<TO, WM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_mfma4_kernel<TO, WM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_done = true;
   }
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
   dim3 grid(kk_cdiv(a.Q, 2 * WM), a.CoutP / BN, B * nphase);
-  hipLaunchKernelGGL((conv_mfma_kernel<TO, WM, NRM>), grid, dim3(256), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_mfma4_kernel<TO, WM, NRM>), grid, dim3(256), G::LDS_BYTES, st, a);
   KK_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace
 
-bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil) {
-  if (Cout % 8 != 0 || Cout < 16 || Cin < 16) return false;  // callers may round a small Cout up to 8 (zero weights)
-  if (mode == KK_CONV && stride != 1) return false;
-  const int ntaps = mode == KK_CONV ? Kw : kk_cdiv(Kw, stride);
-  const int halo = mode == KK_CONV ? (Kw - 1) * dil : (ntaps - 1);
-  return halo <= MAX_HALO;
+// element index of W[tap][cout][k] in the fragment-order pack ([tap][n block][chunk][wc][ni][ks][lane][8])
+long long kk_mfma4_pack_index(int tap, int cout, int k, int CoutP, int CinP) {
+  const int nbk = cout / BN, cr = cout % BN, chunk = k / CK, kr = k % CK;
+  const int wc = cr / 64, ni = (cr % 64) / 32, ks = kr / 16, hh = (kr % 16) / 8, j = kr % 8;
+  const int lane = hh * 32 + (cr % 32);
+  const long long blk = ((long long)tap * (CoutP / BN) + nbk) * (CinP / CK) + chunk;
+  return blk * (BN * CK) + ((long long)(((wc * 2 + ni) * 4 + ks) * 64 + lane)) * 8 + j;
 }
 
-// rows of the output tile a launch with Q rows per phase uses (128 or 192); also the statistics tile size
-int kk_mfma_tile_rows(int Q) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("KK_MFMA_BM");
-    forced = e ? atoi(e) : 0;
+namespace {
+__global__ __launch_bounds__(256) void pack_w_frag_kernel(const bf16_t* w, bf16_t* wf, int Kw, int CoutP, int CinP) {
+  const long long n = (long long)Kw * CoutP * CinP;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int k = (int)(e % CinP);
+    const long long r = e / CinP;
+    const int cout = (int)(r % CoutP), tap = (int)(r / CoutP);
+    const int nbk = cout / BN, cr = cout % BN, chunk = k / CK, kr = k % CK;
+    const int wc = cr / 64, ni = (cr % 64) / 32, ks = kr / 16, hh = (kr % 16) / 8, j = kr % 8;
+    const int lane = hh * 32 + (cr % 32);
+    const long long blk = ((long long)tap * (CoutP / BN) + nbk) * (CinP / CK) + chunk;
+    wf[blk * (BN * CK) + ((long long)(((wc * 2 + ni) * 4 + ks) * 64 + lane)) * 8 + j] = w[e];
   }
-  if (forced == 128 || forced == 192) return forced;
-  (void)Q;
-  // measured (tools/bench_conv.py): 192 rows (3 MFMA row blocks per wave, 250 VGPRs, 73 KB LDS -> still two workgroups per CU)
-  // streams a third less W per MFMA than 128 and is 8-10 % faster on every shape; a 256-row variant spilled and was slower
-  return 192;
+}
+}  // namespace
+
+// device-side re-layout [Kw][CoutP][CinP] -> fragment order (the single-kernel test entry points; the model packs on the host)
+int kk_launch_pack_w_frag(const void* w, void* wf, int Kw, int CoutP, int CinP, hipStream_t st) {
+  if (CinP % CK != 0 || CoutP % BN != 0) return kk_fail("pack_w_frag: CinP must be a multiple of 64 and CoutP of 128");
+  hipLaunchKernelGGL(pack_w_frag_kernel, dim3(1024), dim3(256), 0, st, (const bf16_t*)w, (bf16_t*)wf, Kw, CoutP, CinP);
+  KK_CHECK_LAUNCH();
+  return 0;
 }
 
-int kk_mfma_stat_tile_rows(const KKMfmaArgs& a, int out_dtype) {
-  (void)out_dtype;
-  return kk_mfma_tile_rows(a.Q);
-}
-
-int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st) {
+int kk_launch_conv_mfma4(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st) {
   if (a.Q <= 0 || B <= 0) return 0;
-  if (a.CinP % CK != 0 || a.CoutP % BN != 0) return kk_fail("conv_mfma: CinP must be a multiple of 64 and CoutP of 128");
-  if (a.ldx % 8 != 0 || a.ldo % 8 != 0 || (a.res && a.ldr % 8 != 0)) return kk_fail("conv_mfma: row pitches must be multiples of 8 elements");
-  if (((uintptr_t)a.x & 15) || ((uintptr_t)a.out & 15) || ((uintptr_t)a.res & 15) || ((uintptr_t)a.w & 15))
-    return kk_fail("conv_mfma: pointers must be 16-byte aligned");
-  if (a.ldx < a.CinP) return kk_fail("conv_mfma: input pitch smaller than the padded channel count");
-  if (a.nrm_a && (a.nrm_stride % 4 != 0 || a.nrm_stride < a.CinP)) return kk_fail("conv_mfma: bad AdaIN parameter pitch");
-  const int rows = kk_mfma_tile_rows(a.Q);
+  if (!a.wf) return kk_fail("conv_mfma4: fragment-order weights missing");
   const int nrm = a.nrm_a == nullptr ? 0 : (a.nrm_act == KK_ACT_SNAKE ? 1 : 2);
   KKMfmaArgs g = a;
   if (nrm == 2 && a.nrm_act != KK_ACT_LRELU) g.nrm_slope = 1.0f;  // plain AdaIN: identity activation
-  if (out_dtype != KK_BF16) {
-    if (nrm) return kk_fail("conv_mfma: fused AdaIN input needs a bf16 output");
-    return rows == 192 ? launch_one<float, 96, 0>(g, B, st) : launch_one<float, 64, 0>(g, B, st);
-  }
-  if (rows == 192) {
-    if (nrm == 1) return launch_one<bf16_t, 96, 1>(g, B, st);
-    if (nrm == 2) return launch_one<bf16_t, 96, 2>(g, B, st);
-    return launch_one<bf16_t, 96, 0>(g, B, st);
-  }
-  if (nrm == 1) return launch_one<bf16_t, 64, 1>(g, B, st);
-  if (nrm == 2) return launch_one<bf16_t, 64, 2>(g, B, st);
-  return launch_one<bf16_t, 64, 0>(g, B, st);
+  if (out_dtype != KK_BF16) return kk_fail("conv_mfma4: bf16 output only");
+  if (nrm == 1) return launch_one<bf16_t, 96, 1>(g, B, st);
+  if (nrm == 2) return launch_one<bf16_t, 96, 2>(g, B, st);
+  return launch_one<bf16_t, 96, 0>(g, B, st);
 }

@@ -11,6 +11,7 @@ struct KKMfmaArgs {
   long long xbs;
   int ldx;
   const bf16_t* w;  // packed [Kw][CoutP][CinP], zero padded
+  const bf16_t* wf; // the same weights in MFMA fragment order (kk_mfma4_pack_index); enables the variant-4 kernel
   int CinP, CoutP;
   int Cin;  // channels of x that carry data; [Cin, CinP) are masked to zero while staging (pad channels may hold anything); 0 = CinP
   const float* bias;  // [CoutP] or null
@@ -43,10 +44,10 @@ struct KKMfmaArgs {
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
-// persistent 256-row variant for long sequences (kk_conv_mfma3.hip); kk_launch_conv_mfma dispatches to it
-bool kk_mfma3_usable(const KKMfmaArgs& a, int out_dtype);
-void kk_set_mfma3(int on);
-int kk_launch_conv_mfma3(const KKMfmaArgs& a, int B, hipStream_t st);
+// variant 4 (kk_conv_mfma4.hip): W fragments straight from global memory into the MFMA operand registers; 192-row tiles, bf16 out
+int kk_launch_conv_mfma4(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
+long long kk_mfma4_pack_index(int tap, int cout, int k, int CoutP, int CinP);
+int kk_launch_pack_w_frag(const void* w, void* wf, int Kw, int CoutP, int CinP, hipStream_t st);
 // rows per statistics tile of the kernel kk_launch_conv_mfma will pick for these arguments
 int kk_mfma_stat_tile_rows(const KKMfmaArgs& a, int out_dtype);
 

@@ -18,6 +18,8 @@
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static const void* g_op_wfrag = nullptr;  // kk_debug_set_op_wfrag: fragment-order weights for the single-kernel conv entry points
+
 int kk_fail(const char* msg) {
   g_err = msg ? msg : "unknown error";
   return -1;
@@ -54,9 +56,10 @@ struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
   const float* b = nullptr;
   // bf16 MFMA pack [Kw][CoutP][CinP] (bf16 mode, eligible layers only); bias is then padded to CoutP
   bool mfma = false;
-  size_t wb_off = 0;
+  size_t wb_off = 0, wf_off = 0;
   int CinP = 0, CoutP = 0, Cout8 = 0;
   const bf16_t* wb = nullptr;
+  const bf16_t* wf = nullptr;  // the same weights in MFMA fragment order (variant-4 kernel, kk_mfma4_pack_index)
 };
 struct VecW {
   size_t off = 0;
@@ -157,6 +160,7 @@ struct kk_model {
   std::vector<GraphEntry> graphs;
   unsigned long long* seed_dev = nullptr;  // the Philox seed of a replayed forward
   bool capturing = false;
+  bool no_v4 = false;
   hipStream_t cap_stream = nullptr;
   struct ProfRec { int cls; double flops; double bytes; };
   std::vector<ProfRec> prof_rec;
@@ -351,12 +355,17 @@ struct Packer {
     c.CinP = kk_cdiv(I, 64) * 64;
     c.CoutP = kk_cdiv(O, 128) * 128;
     const size_t nel = (size_t)K * c.CoutP * c.CinP;
-    c.wb_off = alloc((nel + 1) / 2);
+    c.wb_off = alloc((nel + 1) / 2);  // resize() zero-fills
+    c.wf_off = alloc((nel + 1) / 2);  // (may move the staging vector: take the pointers afterwards)
     uint16_t* dst = (uint16_t*)&m->pack[c.wb_off];
-    memset(dst, 0, nel * 2);
+    uint16_t* dfr = (uint16_t*)&m->pack[c.wf_off];
     for (int o = 0; o < O; ++o)
       for (int k = 0; k < K; ++k)
-        for (int i = 0; i < I; ++i) dst[((size_t)k * c.CoutP + o) * c.CinP + i] = f32_to_bf16_rne(wsrc[((size_t)o * K + k) * I + i]);
+        for (int i = 0; i < I; ++i) {
+          const uint16_t v = f32_to_bf16_rne(wsrc[((size_t)o * K + k) * I + i]);
+          dst[((size_t)k * c.CoutP + o) * c.CinP + i] = v;
+          dfr[kk_mfma4_pack_index(k, o, i, c.CoutP, c.CinP)] = v;
+        }
   }
   // pack a conv weight given as wsrc[o][k][i] into [k][i][ldw]
   ConvW pack_oki(const std::vector<float>& wsrc, int O, int K, int I, const std::vector<float>* bias) {
@@ -425,13 +434,17 @@ struct Packer {
     c.CoutP = kk_cdiv(O, 128) * 128;
     const size_t nel = (size_t)K2 * c.CoutP * c.CinP;
     c.wb_off = alloc((nel + 1) / 2);
+    c.wf_off = alloc((nel + 1) / 2);
     uint16_t* dst = (uint16_t*)&m->pack[c.wb_off];
-    memset(dst, 0, nel * 2);
+    uint16_t* dfr = (uint16_t*)&m->pack[c.wf_off];
     for (int o = 0; o < O; ++o)
       for (int t = 0; t < K; ++t) {
         const int tau = fdiv(t - pad, s), j = (t - pad) - tau * s;
-        for (int i = 0; i < I; ++i)
-          dst[((size_t)(tau - tmin) * c.CoutP + o) * c.CinP + j * ld + i] = f32_to_bf16_rne(w[((size_t)o * K + t) * I + i]);
+        for (int i = 0; i < I; ++i) {
+          const uint16_t v = f32_to_bf16_rne(w[((size_t)o * K + t) * I + i]);
+          dst[((size_t)(tau - tmin) * c.CoutP + o) * c.CinP + j * ld + i] = v;
+          dfr[kk_mfma4_pack_index(tau - tmin, o, j * ld + i, c.CoutP, c.CinP)] = v;
+        }
       }
     c.has_bias = true;
     c.b_off = alloc(c.CoutP);
@@ -548,6 +561,7 @@ void resolve(kk_model* m, ConvW& c) {
   c.w = m->dev + c.w_off;
   c.b = c.has_bias ? m->dev + c.b_off : nullptr;
   c.wb = c.mfma ? (const bf16_t*)(m->dev + c.wb_off) : nullptr;
+  c.wf = c.mfma ? (const bf16_t*)(m->dev + c.wf_off) : nullptr;
 }
 void resolve(kk_model* m, VecW& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_model* m, LstmW& l) {
@@ -838,8 +852,11 @@ struct Ctx {
         g.stat_part = fz_part;
         g.stat_ntiles = last_ntiles;
       }
+      // variant 4 (W fragments straight into registers): bf16 outputs at the default 192-row tile
+      const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4 && kk_mfma_tile_rows(Q) == 192;
+      g.wf = v4 ? w.wf : nullptr;
       prof_start();
-      const int rc = kk_launch_conv_mfma(g, B, out.dtype, st);
+      const int rc = v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
       prof_stop(1, flops, bytes);
       return rc;
     }
@@ -1475,7 +1492,7 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
       (unsigned long long)(uintptr_t)ref_s, (unsigned long long)(uintptr_t)speed, (unsigned long long)(uintptr_t)forced_dur,
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
-      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion};
+      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4};
   kk_model::GraphEntry* ge = nullptr;
   for (auto& g : m->graphs)
     if (g.key == key) ge = &g;
@@ -1566,6 +1583,10 @@ extern "C" int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, in
   g.lout = KKLen{lout, lout ? 1 : 0, lout ? 0 : Lout_rows};
   g.in_slope = in_slope; g.scale = scale; g.accumulate = accumulate; g.act = act; g.act_slope = act_slope;
   if (!kk_mfma_eligible(CinP, Cout, Kw, g.mode, stride, dil)) return kk_fail("kk_op_conv1d_bf16: shape not eligible for the MFMA kernel");
+  if (g_op_wfrag && out_dtype == KK_BF16) {
+    g.wf = (const bf16_t*)g_op_wfrag;
+    return kk_launch_conv_mfma4(g, B, out_dtype, (hipStream_t)stream);
+  }
   return kk_launch_conv_mfma(g, B, out_dtype, (hipStream_t)stream);
 }
 
@@ -1588,6 +1609,10 @@ extern "C" int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int l
   g.stat_ntiles = kk_cdiv(L_rows, kk_mfma_stat_tile_rows(g, KK_BF16));
   if (stat_ntiles_out) *stat_ntiles_out = g.stat_ntiles;
   if (!kk_mfma_eligible(CinP, Cout, Kw, KK_CONV, 1, dil)) return kk_fail("kk_op_conv1d_bf16_fused: shape not eligible for the MFMA kernel");
+  if (g_op_wfrag) {
+    g.wf = (const bf16_t*)g_op_wfrag;
+    return kk_launch_conv_mfma4(g, B, KK_BF16, (hipStream_t)stream);
+  }
   return kk_launch_conv_mfma(g, B, KK_BF16, (hipStream_t)stream);
 }
 
@@ -1693,8 +1718,12 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   if (!m) return;
   m->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
   m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
+  m->no_v4 = (on & 4) != 0;          // bit 2: the LDS-staged MFMA kernel (variant 2) instead of variant 4
 }
-extern "C" void kk_debug_set_mfma3(int on) { kk_set_mfma3(on); }
+extern "C" void kk_debug_set_op_wfrag(const void* w_frag) { g_op_wfrag = w_frag; }
+extern "C" int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP) {
+  return kk_launch_pack_w_frag(w_bf16, w_frag, Kw, CoutP, CinP, (hipStream_t)stream);
+}
 extern "C" void kk_debug_clear(kk_model* m) {
   if (!m) return;
   m->dbg_over.clear();

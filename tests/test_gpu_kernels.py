@@ -413,6 +413,30 @@ def pack_w_bf16(w_oki):
     return torch.tensor(p).to(torch.bfloat16), CinP, CoutP
 
 
+_VARIANT4 = False  # set by the `mfma4` fixture: route the kk_op_conv1d_bf16* calls to variant 4 (weights in fragment order)
+
+
+class _wfrag:
+    """Context: re-lay the [Kw][CoutP][CinP] pack out in MFMA fragment order on the device and select variant 4."""
+
+    def __init__(self, lib, wd):
+        self.lib, self.wd, self.on = lib, wd, _VARIANT4
+
+    def __enter__(self):
+        if self.on:
+            K, CoutP, CinP = self.wd.shape
+            self.wf = torch.empty_like(self.wd)
+            rc = self.lib.kk_op_pack_w_frag(stream(), P(self.wd), P(self.wf), K, CoutP, CinP)
+            assert rc == 0, self.lib.kk_last_error()
+            self.lib.kk_debug_set_op_wfrag(P(self.wf))
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            torch.cuda.synchronize()
+            self.lib.kk_debug_set_op_wfrag(None)
+
+
 def run_conv_bf16(lib, x_nlc, w_oki, bias, *, transposed=False, stride=1, pad=0, dil=1, in_shift=0, in_slope=1.0, act=0, act_slope=0.0,
                   res=None, scale=1.0, accumulate=False, out_init=None, Lout=None, lin=None, lout=None, out_f32=False):
     from mlx_audio_amd import _lib
@@ -432,11 +456,12 @@ def run_conv_bf16(lib, x_nlc, w_oki, bias, *, transposed=False, stride=1, pad=0,
     rd = dev(res, odt) if res is not None else None
     lind = dev(np.asarray(lin, np.int32), torch.int32) if lin is not None else None
     loutd = dev(np.asarray(lout, np.int32), torch.int32) if lout is not None else None
-    rc = lib.kk_op_conv1d_bf16(stream(), B, P(xd), CinP, Lin, P(lind), P(wd), CinP, CoutP, P(bd), O_, w_oki.shape[1], int(transposed), stride,
-                               pad, dil, in_shift, in_slope, act, act_slope, P(rd), O_, scale, int(accumulate), P(out), O_, Lout, P(loutd),
-                               _lib.KK_F32 if out_f32 else _lib.KK_BF16)
-    assert rc == 0, lib.kk_last_error()
-    torch.cuda.synchronize()
+    with _wfrag(lib, wd):
+        rc = lib.kk_op_conv1d_bf16(stream(), B, P(xd), CinP, Lin, P(lind), P(wd), CinP, CoutP, P(bd), O_, w_oki.shape[1], int(transposed), stride,
+                                   pad, dil, in_shift, in_slope, act, act_slope, P(rd), O_, scale, int(accumulate), P(out), O_, Lout, P(loutd),
+                                   _lib.KK_F32 if out_f32 else _lib.KK_BF16)
+        assert rc == 0, lib.kk_last_error()
+        torch.cuda.synchronize()
     return out.float().cpu().numpy()
 
 
@@ -456,7 +481,7 @@ MFMA_CASES = [
 
 
 @pytest.mark.parametrize("case", MFMA_CASES, ids=[c[0] for c in MFMA_CASES])
-def test_conv_mfma_bf16(lib, case):
+def test_conv_mfma_bf16(lib, mfma4, case):
     name, Cin, Cout, K, p, d, L = case
     rng = np.random.default_rng(hash(name) % 2**31)
     B = 2
@@ -474,7 +499,7 @@ def test_conv_mfma_bf16(lib, case):
     assert e["rel_max"] < 5e-3  # one bf16 rounding of the result (2^-9 relative)
 
 
-def test_conv_mfma_epilogue_and_ragged(lib):
+def test_conv_mfma_epilogue_and_ragged(lib, mfma4):
     rng = np.random.default_rng(33)
     B, L, C, K, d = 3, 300, 128, 7, 3
     lens = [300, 129, 5]
@@ -559,7 +584,7 @@ def test_lstm_h256_bf16_on_chip(lib):
         assert np.all(got[b, n:] == 0)
 
 
-def test_conv_mfma_fused_adain_snake_and_stats(lib):
+def test_conv_mfma_fused_adain_snake_and_stats(lib, mfma4):
     """Fused form of the bf16 generator: AdaIN + Snake while staging the input, column statistics of the output.
     Reference: the same math in fp32 on the bf16-rounded operands."""
     from mlx_audio_amd import _lib
@@ -586,10 +611,11 @@ def test_conv_mfma_fused_adain_snake_and_stats(lib):
     ntmax = (L + 127) // 128
     part = torch.zeros((B, ntmax, 2, Cn), device="cuda")
     nt = C.c_int(0)
-    rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
-                                     _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
-    assert rc == 0, lib.kk_last_error()
-    torch.cuda.synchronize()
+    with _wfrag(lib, wd):
+        rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
+                                         _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
+        assert rc == 0, lib.kk_last_error()
+        torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     pt = part.cpu().numpy().reshape(-1)[: B * nt.value * 2 * Cn].reshape(B, nt.value, 2, Cn)
     for b, n in enumerate(lens):
@@ -617,15 +643,17 @@ LONG_CASES = [
 ]
 
 
-@pytest.fixture
-def mfma3(lib):
-    lib.kk_debug_set_mfma3(1)
-    yield
-    lib.kk_debug_set_mfma3(0)
+@pytest.fixture(params=[False, True], ids=["lds_staged", "variant4"])
+def mfma4(request):
+    """Both bf16 MFMA kernels: the LDS-staged one and variant 4 (W fragments straight from global memory into registers)."""
+    global _VARIANT4
+    _VARIANT4 = request.param
+    yield request.param
+    _VARIANT4 = False
 
 
 @pytest.mark.parametrize("case", LONG_CASES, ids=[c[0] for c in LONG_CASES])
-def test_conv_mfma3_long(lib, mfma3, case):
+def test_conv_mfma_long(lib, mfma4, case):
     name, Cin, Cout, K, p, d, L = case
     rng = np.random.default_rng(hash(name) % 2**31)
     B = 3
@@ -644,16 +672,16 @@ def test_conv_mfma3_long(lib, mfma3, case):
         base = F.conv1d(torch.tensor(xin)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, p, d).transpose(1, 2)[0]
         ref = ((base + torch.tensor(res[b, :n])) * (1 / 3) + torch.tensor(init[b, :n])).numpy()
         e = err_stats(got[b, :n], ref)
-        report(f"conv_mfma3/{name}/b{b}", **e)
+        report(f"conv_mfma{4 if mfma4 else 2}/{name}/b{b}", **e)
         assert e["rel_max"] < 6e-3
         assert np.all(got[b, n:] == 0)
 
 
-def test_conv_mfma3_transposed_and_fused(lib, mfma3):
+def test_conv_mfma_transposed_and_fused(lib, mfma4):
     from mlx_audio_amd import _lib
 
     rng = np.random.default_rng(123)
-    # transposed conv (ups.1 geometry) on the persistent kernel: Q = L >= 2048 rows per phase
+    # transposed conv (ups.1 geometry), long rows
     K, s, p, Cin, Cout, L, B = 12, 6, 3, 256, 128, 2200, 2
     x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
     w_iko = _bf((rng.standard_normal((Cin, K, Cout)) / math.sqrt(K * Cin / s)).astype(np.float32))
@@ -661,7 +689,7 @@ def test_conv_mfma3_transposed_and_fused(lib, mfma3):
     ref = F.conv_transpose1d(torch.tensor(x).transpose(1, 2), torch.tensor(w_iko).permute(0, 2, 1), torch.tensor(b), s, p).transpose(1, 2).numpy()
     got = run_conv_bf16(lib, x, np.transpose(w_iko, (2, 1, 0)), b, transposed=True, stride=s, pad=p, Lout=ref.shape[1])
     e = err_stats(got, ref)
-    report("conv_mfma3/convT_k12s6", **e)
+    report(f"conv_mfma{4 if mfma4 else 2}/convT_k12s6", **e)
     assert e["rel_max"] < 6e-3
     # fused AdaIN + Snake input and output statistics
     L, Cn, K, d = 2600, 128, 7, 3
@@ -684,10 +712,11 @@ def test_conv_mfma3_transposed_and_fused(lib, mfma3):
     out = torch.full((B, L, Cn), 7.0, device="cuda", dtype=torch.bfloat16)
     part = torch.zeros((B, (L + 127) // 128, 2, Cn), device="cuda")
     nt = C.c_int(0)
-    rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
-                                     _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
-    assert rc == 0, lib.kk_last_error()
-    torch.cuda.synchronize()
+    with _wfrag(lib, wd):
+        rc = lib.kk_op_conv1d_bf16_fused(stream(), B, P(xd), Cn, L, P(lend), P(wd), CinP, CoutP, P(bd), Cn, Cn, K, 9, d, P(ad), P(bvd), Cn,
+                                         _lib.ACT_SNAKE, 0.0, P(ald), P(rd), Cn, 1.0, P(out), Cn, P(part), C.byref(nt))
+        assert rc == 0, lib.kk_last_error()
+        torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     pt = part.cpu().numpy().reshape(-1)[: B * nt.value * 2 * Cn].reshape(B, nt.value, 2, Cn)  # pitch = the kernel's tile count
     for bb, n in enumerate(lens):
@@ -697,7 +726,7 @@ def test_conv_mfma3_transposed_and_fused(lib, mfma3):
         base = F.conv1d(torch.tensor(y)[None].transpose(1, 2), torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 9, d).transpose(1, 2)[0]
         ref = (base + torch.tensor(res[bb, :n])).numpy()
         e = err_stats(got[bb, :n], ref)
-        report(f"conv_mfma3/fused/b{bb}", **e)
+        report(f"conv_mfma{4 if mfma4 else 2}/fused/b{bb}", **e)
         assert e["rel_max"] < 1.5e-2
         assert np.all(got[bb, n:] == 0)
         np.testing.assert_allclose(pt[bb, :, 0].sum(0), got[bb, :n].sum(0), rtol=1e-3, atol=5e-2)

@@ -55,6 +55,10 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
                                    1.0, 0, P(out), Cout, L, None, _lib.KK_BF16)
         assert rc == 0, lib.kk_last_error()
 
+    if V4:  # variant 4: weights in MFMA fragment order, straight from global memory into the operand registers
+        wf = torch.empty_like(w)
+        assert lib.kk_op_pack_w_frag(st(), P(w), P(wf), K, CoutP, CinP) == 0
+        lib.kk_debug_set_op_wfrag(P(wf))
     call = call_fused if fused else call_plain
     call()
     torch.cuda.synchronize()
@@ -78,11 +82,16 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
                  "main.x_barrier_transform": buf[3] // n, "epi.acc_in_lds": buf[6] // n, "epi.pass0_stored": buf[7] // n, "total_to_store_end": buf[4] // n}
     fl = 2.0 * B * L * Cin * Cout * K
     by = B * L * (Cin + Cout * (2 if res else 1)) * 2
-    out = {"name": name + ("+fused" if fused else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+    if V4:
+        torch.cuda.synchronize()
+        lib.kk_debug_set_op_wfrag(None)
+    out = {"name": name + ("+fused" if fused else "") + ("+v4" if V4 else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
     if trace:
         out["trace_cycles"] = trace
     return out
 
+
+V4 = "--v4" in sys.argv
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
