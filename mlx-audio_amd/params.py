@@ -313,3 +313,92 @@ def to_torch_layout(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         else:
             out[k] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mimi codec (decode path): configuration mirrors mimi_202407 (mlx_audio/codec/models/mimi/mimi.py:41-101)
+# ---------------------------------------------------------------------------------------------------------------------
+def mimi_config(num_codebooks: int = 32) -> dict:
+    return dict(dim=512, nq=num_codebooks, bins=2048, qdim=256, num_heads=8, num_layers=8, dim_feedforward=2048, nfilters=64,
+                ratios=[8, 6, 5, 4], ksize=7, residual_ksize=3, last_ksize=3, upsample_stride=2, rope_base=10000, compress=2,
+                sample_rate=24000, frame_rate=12.5)
+
+
+def mimi_tiny_config() -> dict:
+    """Same topology, small widths (head_dim stays 64): unit tests."""
+    return dict(dim=128, nq=4, bins=64, qdim=32, num_heads=2, num_layers=2, dim_feedforward=256, nfilters=8,
+                ratios=[8, 6, 5, 4], ksize=7, residual_ksize=3, last_ksize=3, upsample_stride=2, rope_base=10000, compress=2,
+                sample_rate=24000, frame_rate=12.5)
+
+
+def mimi_param_inventory(cfg: dict) -> dict:
+    """MLX-side names and shapes of everything Mimi.decode reads (after load_pytorch_weights' remap, mimi.py:184-249)."""
+    D, Q = cfg["dim"], cfg["qdim"]
+    inv = {}
+    for which, n in (("rvq_first", 1), ("rvq_rest", cfg["nq"] - 1)):
+        for i in range(n):
+            inv[f"quantizer.{which}.vq.layers.{i}.codebook.embedding_sum"] = (cfg["bins"], Q)
+            inv[f"quantizer.{which}.vq.layers.{i}.codebook.cluster_usage"] = (cfg["bins"],)
+        if n > 0:
+            inv[f"quantizer.{which}.output_proj.weight"] = (D, 1, Q)
+    inv["upsample.convtr.convtr.convtr.weight"] = (1, 2 * cfg["upsample_stride"], D)
+    for i in range(cfg["num_layers"]):
+        p = f"decoder_transformer.transformer.layers.{i}"
+        for nm in ("norm1", "norm2"):
+            inv[f"{p}.{nm}.weight"] = (D,)
+            inv[f"{p}.{nm}.bias"] = (D,)
+        inv[f"{p}.self_attn.in_proj.weight"] = (3 * D, D)
+        inv[f"{p}.self_attn.out_proj.weight"] = (D, D)
+        inv[f"{p}.layer_scale_1.scale"] = (D,)
+        inv[f"{p}.layer_scale_2.scale"] = (D,)
+        inv[f"{p}.gating.linear1.weight"] = (cfg["dim_feedforward"], D)
+        inv[f"{p}.gating.linear2.weight"] = (D, cfg["dim_feedforward"])
+    mult = 1 << len(cfg["ratios"])
+    nf = cfg["nfilters"]
+    inv["decoder.init_conv1d.conv.conv.weight"] = (mult * nf, cfg["ksize"], D)
+    inv["decoder.init_conv1d.conv.conv.bias"] = (mult * nf,)
+    for l, r in enumerate(cfg["ratios"]):
+        cin, cout = mult * nf, mult * nf // 2
+        p = f"decoder.layers.{l}"
+        inv[f"{p}.upsample.convtr.convtr.weight"] = (cout, 2 * r, cin)
+        inv[f"{p}.upsample.convtr.convtr.bias"] = (cout,)
+        hid = cout // cfg["compress"]
+        inv[f"{p}.residuals.0.block.0.conv.conv.weight"] = (hid, cfg["residual_ksize"], cout)
+        inv[f"{p}.residuals.0.block.0.conv.conv.bias"] = (hid,)
+        inv[f"{p}.residuals.0.block.1.conv.conv.weight"] = (cout, 1, hid)
+        inv[f"{p}.residuals.0.block.1.conv.conv.bias"] = (cout,)
+        mult //= 2
+    inv["decoder.final_conv1d.conv.conv.weight"] = (1, cfg["last_ksize"], nf)
+    inv["decoder.final_conv1d.conv.conv.bias"] = (1,)
+    return inv
+
+
+def mimi_synth_checkpoint(cfg: dict, seed: int = 0) -> dict:
+    """Seeded random-init decode-side checkpoint (fan-in scaled so activations stay O(1); no real weights exist offline)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in mimi_param_inventory(cfg).items():
+        if name.endswith("embedding_sum"):
+            w[name] = (0.25 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("cluster_usage"):
+            u = rng.uniform(0.5, 2.0, shape).astype(np.float32)
+            u[:2] = 0.0  # two never-used entries: the 1e-5 floor of quantization.py:25 is exercised ...
+            w[name] = u
+        elif name.endswith("layer_scale_1.scale") or name.endswith("layer_scale_2.scale"):
+            w[name] = rng.uniform(0.05, 0.4, shape).astype(np.float32)
+        elif name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif name.endswith(".bias"):
+            w[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            if name.endswith("convtr.weight") and len(shape) == 3 and shape[0] > 1:
+                fan_in = shape[2] * 2  # two taps of a k = 2*stride transposed conv reach an output sample
+            if name.startswith("upsample."):
+                fan_in = 2
+            gain = 0.5 if ".block.1." in name else 1.0
+            w[name] = (rng.standard_normal(shape) * (gain / np.sqrt(fan_in))).astype(np.float32)
+    for name in list(w):
+        if name.endswith("cluster_usage"):
+            w[name.replace("cluster_usage", "embedding_sum")][:2] = 0.0  # ... without producing 1e5-scale rows
+    return w

@@ -1,0 +1,148 @@
+"""CPU restatement (PyTorch-CPU fp32) of the reference's Mimi codec DECODE path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench tools' cpu_baseline legs may import this file; the product path
+(mlx-audio_amd/) never does.
+
+Follows, as text (reference paths relative to the repository root):
+  mlx_audio/codec/models/mimi/mimi.py:147-154            Mimi.decode
+  mlx_audio/codec/models/mimi/modules/quantization.py    EuclideanCodebook.decode :41-43, embedding = embedding_sum /
+                                                         max(cluster_usage, 1e-5) :25-28, split RVQ decode :97-101,135-139,178-182
+  mlx_audio/codec/models/mimi/modules/conv.py            causal StreamableConv1d :244-263, StreamableConvTranspose1d :323-333,
+                                                         depth-wise ConvTrUpsample1d :379-401 (eye-masked dense weight :82-95)
+  mlx_audio/codec/models/mimi/modules/transformer.py     Attention :62-104 (RoPE traditional, base 10000; **no mask is passed in the
+                                                         non-streaming call**, so decode() attends bidirectionally), MlpNoGating
+                                                         :126-134 (gelu_approx), TransformerLayer :137-177 (LayerScale), ProjectedTransformer
+  mlx_audio/codec/models/mimi/modules/seanet.py          SeanetResnetBlock :55-116, DecoderLayer :189-225, SeanetDecoder :228-283
+
+PARITY WITH MLX IS UNPINNED: `mlx` is not installable here and the reference's only Mimi test
+(mlx_audio/codec/tests/test_mimi.py) pins shapes only -- codes [1,32,63] -> pcm [1,1,120960]; that known answer is
+checked in tests/test_mimi_oracle.py.  MLX op semantics assumed (upstream knowledge, not in tree): conv weights [O,K,I]
+channels-last, conv_transpose1d without kernel flip (mimi.py:228-237 maps PyTorch [I,O,K] -> transpose(1,2,0)),
+nn.gelu_approx = tanh form, nn.RoPE(traditional=True) rotates (x[2i], x[2i+1]) by pos * base^(-2i/D).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def t(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32)
+
+
+class MimiOracle:
+    def __init__(self, w: dict, cfg: dict):
+        self.w = {k: np.asarray(v, np.float32) for k, v in w.items()}
+        self.cfg = cfg
+
+    # ---- quantization.py ----------------------------------------------------------------------------------------
+    def codebook(self, prefix: str) -> torch.Tensor:
+        usage = np.maximum(self.w[prefix + ".cluster_usage"], 1e-5)[:, None]  # quantization.py:25-28
+        return t(self.w[prefix + ".embedding_sum"] / usage)
+
+    def rvq_decode(self, which: str, codes: np.ndarray) -> torch.Tensor:
+        """codes [B, n, Nf] -> [B, dim, Nf]: sum of code-book rows (:97-101), then the 1x1 output projection (:135-139)."""
+        q = None
+        for i in range(codes.shape[1]):
+            e = self.codebook(f"quantizer.{which}.vq.layers.{i}.codebook")[torch.as_tensor(codes[:, i].astype(np.int64))]  # [B,Nf,256]
+            q = e if q is None else q + e
+        q = q.transpose(1, 2)  # [B,256,Nf]
+        w = t(self.w[f"quantizer.{which}.output_proj.weight"]).permute(0, 2, 1)  # MLX [O,K,I] -> torch [O,I,K]
+        return F.conv1d(q, w)
+
+    def quantizer_decode(self, codes: np.ndarray) -> torch.Tensor:
+        q = self.rvq_decode("rvq_first", codes[:, :1])
+        if codes.shape[1] > 1:
+            q = q + self.rvq_decode("rvq_rest", codes[:, 1:])  # quantization.py:178-182
+        return q
+
+    # ---- conv.py -------------------------------------------------------------------------------------------------
+    def causal_conv(self, x: torch.Tensor, prefix: str, dilation: int = 1) -> torch.Tensor:
+        """StreamableConv1d.__call__ (:244-263), causal, stride 1: left pad (k-1)*d, pad_mode 'constant' (zeros)."""
+        w = t(self.w[prefix + ".conv.conv.weight"])  # [O,K,I]
+        b = t(self.w[prefix + ".conv.conv.bias"]) if prefix + ".conv.conv.bias" in self.w else None
+        k = w.shape[1]
+        pad = (k - 1) * dilation
+        return F.conv1d(F.pad(x, (pad, 0)), w.permute(0, 2, 1), b, dilation=dilation)
+
+    def causal_convtr(self, x: torch.Tensor, prefix: str, stride: int) -> torch.Tensor:
+        """StreamableConvTranspose1d.__call__ (:323-333), causal: full transposed conv, then the last k - stride samples go."""
+        w = t(self.w[prefix + ".convtr.convtr.weight"])  # MLX [O,K,I]
+        b = t(self.w[prefix + ".convtr.convtr.bias"]) if prefix + ".convtr.convtr.bias" in self.w else None
+        k = w.shape[1]
+        y = F.conv_transpose1d(x, w.permute(2, 0, 1), b, stride=stride)
+        return y[..., : y.shape[-1] - max(k - stride, 0)]
+
+    def upsample(self, x: torch.Tensor) -> torch.Tensor:
+        """ConvTrUpsample1d (:379-401): depth-wise transposed conv k = 2*stride, no bias, causal."""
+        s = self.cfg["upsample_stride"]
+        w = t(self.w["upsample.convtr.convtr.convtr.weight"])  # [1, 2s, C]
+        C = w.shape[2]
+        y = F.conv_transpose1d(x, w[0].transpose(0, 1)[:, None, :], None, stride=s, groups=C)
+        return y[..., : y.shape[-1] - s]
+
+    # ---- transformer.py ------------------------------------------------------------------------------------------
+    def rope(self, x: torch.Tensor) -> torch.Tensor:
+        """nn.RoPE(head_dim, traditional=True, base=max_period), offset 0; x [B,H,T,D]."""
+        D = x.shape[-1]
+        pos = torch.arange(x.shape[2], dtype=torch.float32)[:, None]
+        inv = torch.tensor(float(self.cfg["rope_base"]), dtype=torch.float32) ** (-torch.arange(0, D // 2, dtype=torch.float32) / (D // 2))
+        ang = pos * inv[None, :]
+        c, s = torch.cos(ang), torch.sin(ang)
+        x0, x1 = x[..., 0::2], x[..., 1::2]
+        out = torch.empty_like(x)
+        out[..., 0::2] = x0 * c - x1 * s
+        out[..., 1::2] = x0 * s + x1 * c
+        return out
+
+    def transformer(self, x: torch.Tensor) -> torch.Tensor:
+        """ProjectedTransformer with conv_layout (:213-247): [B,C,T] -> [B,T,C] -> layers -> back."""
+        cfg = self.cfg
+        H = cfg["num_heads"]
+        x = x.transpose(1, 2)
+        Bn, T, C = x.shape
+        hd = C // H
+        for i in range(cfg["num_layers"]):
+            p = f"decoder_transformer.transformer.layers.{i}"
+            n1 = F.layer_norm(x, (C,), t(self.w[p + ".norm1.weight"]), t(self.w[p + ".norm1.bias"]), 1e-5)
+            qkv = (n1 @ t(self.w[p + ".self_attn.in_proj.weight"]).T).reshape(Bn, T, 3, H, hd)
+            q, k, v = [qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3)]
+            q, k = self.rope(q), self.rope(k)
+            att = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v  # mask=None in the reference call (:171)
+            att = att.permute(0, 2, 1, 3).reshape(Bn, T, C) @ t(self.w[p + ".self_attn.out_proj.weight"]).T
+            x = x + att * t(self.w[p + ".layer_scale_1.scale"])
+            n2 = F.layer_norm(x, (C,), t(self.w[p + ".norm2.weight"]), t(self.w[p + ".norm2.bias"]), 1e-5)
+            h = n2 @ t(self.w[p + ".gating.linear1.weight"]).T
+            h = 0.5 * h * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (h + 0.044715 * h ** 3)))  # nn.gelu_approx
+            x = x + (h @ t(self.w[p + ".gating.linear2.weight"]).T) * t(self.w[p + ".layer_scale_2.scale"])
+        return x.transpose(1, 2)
+
+    # ---- seanet.py -----------------------------------------------------------------------------------------------
+    def seanet_decoder(self, x: torch.Tensor, inter: dict | None = None) -> torch.Tensor:
+        x = self.causal_conv(x, "decoder.init_conv1d")
+        for l, r in enumerate(self.cfg["ratios"]):
+            p = f"decoder.layers.{l}"
+            x = self.causal_convtr(F.elu(x), p + ".upsample", r)
+            res = x
+            y = self.causal_conv(F.elu(x), p + ".residuals.0.block.0", 1)
+            y = self.causal_conv(F.elu(y), p + ".residuals.0.block.1", 1)
+            x = y + res  # true_skip
+            if inter is not None:
+                inter[f"layer{l}"] = x.numpy()
+        return self.causal_conv(F.elu(x), "decoder.final_conv1d")
+
+    # ---- mimi.py:147-154 -------------------------------------------------------------------------------------------
+    def decode(self, codes: np.ndarray, return_inter: bool = False):
+        with torch.no_grad():
+            inter = {}
+            x = self.quantizer_decode(np.asarray(codes))
+            inter["quantized"] = x.numpy()
+            x = self.upsample(x)
+            inter["upsampled"] = x.numpy()
+            x = self.transformer(x)
+            inter["transformer"] = x.numpy()
+            pcm = self.seanet_decoder(x, inter).numpy()
+        return (pcm, inter) if return_inter else pcm

@@ -1,0 +1,45 @@
+"""CPU checks of the Mimi decode oracle: the reference's only known answer (shapes, mlx_audio/codec/tests/test_mimi.py:9-19)
+and the structural properties the restatement must have."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import mimi_oracle as M  # noqa: E402
+import mlx_audio_amd.params as P  # noqa: E402
+
+
+def test_reference_shape_known_answer():
+    """test_mimi.py: codes [1, 32, 63] decode to pcm [1, 1, 120960] (1920 samples per 12.5 Hz frame)."""
+    cfg = P.mimi_config(32)
+    w = P.mimi_synth_checkpoint(cfg, 0)
+    assert abs(sum(int(np.prod(s)) for s in P.mimi_param_inventory(cfg).values()) - 57.0e6) < 0.1e6
+    codes = np.zeros((1, 32, 63), np.int64)
+    pcm = M.MimiOracle(w, cfg).decode(codes)
+    assert pcm.shape == (1, 1, 120960) and np.isfinite(pcm).all()
+
+
+def test_decode_is_batch_independent_and_not_causal_in_the_transformer():
+    cfg = P.mimi_tiny_config()
+    w = P.mimi_synth_checkpoint(cfg, 1)
+    orc = M.MimiOracle(w, cfg)
+    rng = np.random.default_rng(0)
+    codes = rng.integers(0, cfg["bins"], (3, cfg["nq"], 9))
+    pcm, inter = orc.decode(codes, return_inter=True)
+    assert pcm.shape == (3, 1, 1920 * 9)
+    for b in range(3):
+        np.testing.assert_allclose(orc.decode(codes[b : b + 1])[0], pcm[b], rtol=1e-5, atol=1e-5)
+    # everything but the transformer is causal: changing the LAST frame's codes must not move the quantizer / upsample output
+    # of earlier frames, but (mask=None, transformer.py:171) it does move the transformer output at t = 0
+    c2 = codes.copy()
+    c2[:, :, -1] = (c2[:, :, -1] + 1) % cfg["bins"]
+    _, i2 = orc.decode(c2, return_inter=True)
+    np.testing.assert_array_equal(inter["upsampled"][..., :16], i2["upsampled"][..., :16])
+    assert np.abs(inter["transformer"][..., 0] - i2["transformer"][..., 0]).max() > 1e-6
+    # never-used code-book entries (cluster_usage = 0) decode through the 1e-5 floor (quantization.py:25-28)
+    c3 = np.zeros_like(codes)
+    assert np.isfinite(orc.decode(c3)).all()
