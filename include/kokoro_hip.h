@@ -174,6 +174,37 @@ void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: 
 int kk_profile_begin(kk_model* m, int max_launches);
 int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count);
 
+/* =====================================================================================================================
+ * Mimi codec, decode path (CSM row C4): Mimi.decode, mlx_audio/codec/models/mimi/mimi.py:147-154.
+ * Same conventions as above: device pointers, caller-owned buffers, work enqueued on `stream`, 0 = OK.
+ * ===================================================================================================================== */
+typedef struct kk_mimi kk_mimi;
+
+/* mimi_202407 (mimi.py:41-101): dim 512, nq 32, bins 2048, qdim 256, 8 heads, 8 layers, ff 2048, nfilters 64,
+ * ratios {8,6,5,4}, ksize 7, residual_ksize 3, last_ksize 3, upsample_stride 2, compress 2, rope_base 10000 */
+typedef struct kk_mimi_config {
+  int32_t dim, nq, bins, qdim, num_heads, num_layers, dim_feedforward, nfilters;
+  int32_t n_ratios, ratios[8];
+  int32_t ksize, residual_ksize, last_ksize, upsample_stride, compress;
+  float rope_base;
+  int32_t compute_dtype; /* KK_F32 (round 1) */
+} kk_mimi_config;
+
+int kk_mimi_create(const kk_mimi_config* cfg, kk_mimi** out);
+void kk_mimi_destroy(kk_mimi* m);
+/* parameters by their MLX-side names (after Mimi.load_pytorch_weights' remap, mimi.py:184-249), host fp32, MLX layouts:
+ * conv / conv-transpose weights [O][K][I], code books as embedding_sum [bins][qdim] + cluster_usage [bins] */
+int kk_mimi_load_tensor(kk_mimi* m, const char* name, const int64_t* shape, int ndim, const float* data);
+int kk_mimi_finalize(kk_mimi* m, void* stream); /* code books divided by max(usage, 1e-5) (quantization.py:25-28), LayerScale folded, upload */
+int64_t kk_mimi_samples_per_frame(const kk_mimi* m); /* 1920 for mimi_202407 */
+size_t kk_mimi_workspace_bytes(kk_mimi* m, int B, int Nf);
+/* codes [B][nq][Nf] int32 (device) -> pcm [B][samples_per_frame * Nf] float32 (device).  Like the reference's non-streaming
+ * decode the transformer attends over the WHOLE sequence (no mask reaches the attention call, transformer.py:171). */
+int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);
+/* intermediates of the last decode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3"; [B][rows][channels] fp32 */
+int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels);
+int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,16 @@ class KKConfig(C.Structure):
     ]
 
 
+class KKMimiConfig(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("nq", C.c_int32), ("bins", C.c_int32), ("qdim", C.c_int32), ("num_heads", C.c_int32),
+        ("num_layers", C.c_int32), ("dim_feedforward", C.c_int32), ("nfilters", C.c_int32),
+        ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8),
+        ("ksize", C.c_int32), ("residual_ksize", C.c_int32), ("last_ksize", C.c_int32), ("upsample_stride", C.c_int32),
+        ("compress", C.c_int32), ("rope_base", C.c_float), ("compute_dtype", C.c_int32),
+    ]
+
+
 # every symbol include/kokoro_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
@@ -57,6 +67,15 @@ SIGNATURES = {
     "kk_debug_clear": (None, [_vp]),
     "kk_debug_force_generic": (None, [_vp, _i]),
     "kk_op_pack_w_frag": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kk_mimi_create": (_i, [C.POINTER(KKMimiConfig), C.POINTER(_vp)]),
+    "kk_mimi_destroy": (None, [_vp]),
+    "kk_mimi_load_tensor": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), _i, _vp]),
+    "kk_mimi_finalize": (_i, [_vp, _vp]),
+    "kk_mimi_samples_per_frame": (C.c_int64, [_vp]),
+    "kk_mimi_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "kk_mimi_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "kk_mimi_debug_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "kk_mimi_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_set_op_wfrag": (None, [_vp]),
     "kk_set_graph_mode": (_i, [_vp, _i]),
     "kk_profile_begin": (_i, [_vp, _i]),

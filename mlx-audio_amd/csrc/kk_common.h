@@ -18,7 +18,7 @@ typedef __bf16 bf16_t;
 template <typename T> __device__ __forceinline__ float kk_ld(const T* p) { return (float)(*p); }
 template <typename T> __device__ __forceinline__ void kk_st(T* p, float v) { *p = (T)v; }
 
-enum KKAct { KK_ACT_NONE = 0, KK_ACT_LRELU = 1, KK_ACT_GELU = 2, KK_ACT_SNAKE = 3 };
+enum KKAct { KK_ACT_NONE = 0, KK_ACT_LRELU = 1, KK_ACT_GELU = 2, KK_ACT_SNAKE = 3, KK_ACT_GELU_TANH = 4, KK_ACT_ELU = 5 };
 enum KKConvMode { KK_CONV = 0, KK_CONVT = 1 };
 enum KKDType { KK_F32 = 0, KK_BF16 = 1, KK_I32 = 2, KK_F16 = 3 };
 
@@ -55,6 +55,7 @@ struct KKConvArgs {
   int accumulate;     // epilogue: v += out
   int act;            // epilogue activation (KKAct) applied to acc+bias, before residual/scale
   float act_slope;
+  int in_act;         // 0: leaky-relu(in_slope) on the input (identity at 1.0); KK_ACT_ELU: elu(x, 1) on the input (Mimi SEANet)
 };
 
 __host__ __device__ static inline int kk_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(KKConvArgs a) {
         for (int i = 0; i < 8; ++i) {
           const int c = c0 + ak0 + i;
           float v = (rv && c < a.Cin) ? kk_ld(xr + c) : 0.f;
-          av[i] = v > 0.f ? v : v * a.in_slope;
+          av[i] = a.in_act == KK_ACT_ELU ? (v > 0.f ? v : expf(v) - 1.0f)  // nn.elu: where(x > 0, x, exp(x) - 1)
+                                          : (v > 0.f ? v : v * a.in_slope);
         }
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 + bk < a.Cin) bv = *(const float4*)(wt + (long long)(c0 + bk) * a.ldw + co0 + bn);
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(KKConvArgs a) {
         v = acc[i][j] + (a.bias ? a.bias[co] : 0.f);
         if (a.act == KK_ACT_LRELU) v = v > 0.f ? v : v * a.act_slope;
         else if (a.act == KK_ACT_GELU) v = gelu_exact(v);
+        else if (a.act == KK_ACT_GELU_TANH) v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));  // nn.gelu_approx
         if (rb) v += kk_ld(rb + (long long)op * a.ldr + co);
         v *= a.scale;
         if (a.accumulate) v += kk_ld(ob + (long long)op * a.ldo + co);

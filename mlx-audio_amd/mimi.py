@@ -1,0 +1,130 @@
+"""Host mirror of the reference's Mimi codec surface for the DECODE path (mlx_audio/codec/models/mimi/mimi.py): `mimi_202407`,
+`Mimi(cfg)`, `Mimi.decode(codes)`, `.sample_rate`, `.frame_rate`.  The arithmetic runs in libkokoro_hip.so (kk_mimi_*, csrc/kk_mimi.hip);
+PyTorch allocates device memory and provides the stream.  Encoding (Mimi.encode, mimi.py:138-145) is not built."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KokoroHipError, check
+
+
+@dataclass
+class MimiConfig:
+    """The fields of MimiConfig / SeanetConfig / TransformerConfig (mimi.py:27-38) that the decode path reads."""
+    dim: int = 512
+    nq: int = 32
+    bins: int = 2048
+    qdim: int = 256
+    num_heads: int = 8
+    num_layers: int = 8
+    dim_feedforward: int = 2048
+    nfilters: int = 64
+    ratios: List[int] = field(default_factory=lambda: [8, 6, 5, 4])
+    ksize: int = 7
+    residual_ksize: int = 3
+    last_ksize: int = 3
+    upsample_stride: int = 2
+    compress: int = 2
+    rope_base: float = 10000.0
+    sample_rate: float = 24000.0
+    frame_rate: float = 12.5
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "MimiConfig":
+        return cls(**{k: v for k, v in d.items() if k in cls.__dataclass_fields__})
+
+
+def mimi_202407(num_codebooks: int) -> MimiConfig:
+    """mimi.py:41-101."""
+    return MimiConfig(nq=num_codebooks)
+
+
+class Mimi:
+    def __init__(self, cfg: MimiConfig, weights: Dict[str, np.ndarray] | None = None, device: str = "cuda:0"):
+        self.cfg = cfg
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise KokoroHipError("Mimi needs a GPU: the decode path has no CPU fallback")
+        self.device = torch.device(device)
+        kc = _lib.KKMimiConfig()
+        for k in ("dim", "nq", "bins", "qdim", "num_heads", "num_layers", "dim_feedforward", "nfilters", "ksize", "residual_ksize", "last_ksize",
+                  "upsample_stride", "compress"):
+            setattr(kc, k, int(getattr(cfg, k)))
+        kc.n_ratios = len(cfg.ratios)
+        for i, r in enumerate(cfg.ratios):
+            kc.ratios[i] = int(r)
+        kc.rope_base = float(cfg.rope_base)
+        kc.compute_dtype = _lib.KK_F32
+        h = C.c_void_p()
+        check(self.lib.kk_mimi_create(C.byref(kc), C.byref(h)), "kk_mimi_create")
+        self._h = h
+        self._final = False
+        self._ws = None
+        if weights is not None:
+            self.load_weights(weights)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.kk_mimi_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> "Mimi":
+        """MLX-side names and layouts (what Mimi.load_pytorch_weights produces, mimi.py:184-249).  Unknown names are ignored the way
+        `strict=False` would; missing ones fail in finalize with the parameter's name."""
+        with torch.cuda.device(self.device):
+            for name, arr in weights.items():
+                a = np.ascontiguousarray(np.asarray(arr, np.float32))
+                shp = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+                check(self.lib.kk_mimi_load_tensor(self._h, name.encode(), shp, max(a.ndim, 1), a.ctypes.data_as(C.c_void_p)), "kk_mimi_load_tensor")
+            check(self.lib.kk_mimi_finalize(self._h, self._stream()), "kk_mimi_finalize")
+        self._final = True
+        return self
+
+    @property
+    def frame_rate(self) -> float:
+        return self.cfg.frame_rate
+
+    @property
+    def sample_rate(self) -> float:
+        return self.cfg.sample_rate
+
+    def decode(self, codes) -> torch.Tensor:
+        """codes [B, nq, Nf] integer -> pcm [B, 1, 1920 * Nf] float32 on the device (mimi.py:147-154)."""
+        if not self._final:
+            raise KokoroHipError("Mimi.decode: load_weights first")
+        codes = torch.as_tensor(codes).to(device=self.device, dtype=torch.int32).contiguous()
+        if codes.ndim != 3 or codes.shape[1] != self.cfg.nq:
+            raise ValueError(f"codes must be [B, {self.cfg.nq}, Nf], got {tuple(codes.shape)}")
+        B, _, Nf = codes.shape
+        self._last_B = B
+        with torch.cuda.device(self.device):
+            need = int(self.lib.kk_mimi_workspace_bytes(self._h, B, Nf))
+            if need == 0:
+                raise KokoroHipError("kk_mimi_workspace_bytes failed")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            spf = int(self.lib.kk_mimi_samples_per_frame(self._h))
+            pcm = torch.empty((B, 1, spf * Nf), dtype=torch.float32, device=self.device)
+            check(self.lib.kk_mimi_decode(self._h, self._stream(), B, Nf, C.c_void_p(codes.data_ptr()), C.c_void_p(self._ws.data_ptr()), need,
+                                          C.c_void_p(pcm.data_ptr())), "kk_mimi_decode")
+        return pcm
+
+    def debug_fetch(self, name: str) -> torch.Tensor:
+        rows, ch = C.c_int64(0), C.c_int64(0)
+        check(self.lib.kk_mimi_debug_info(self._h, name.encode(), C.byref(rows), C.byref(ch)), "kk_mimi_debug_info")
+        B = self._last_B
+        out = torch.empty((B, rows.value, ch.value), dtype=torch.float32, device=self.device)
+        check(self.lib.kk_mimi_debug_fetch(self._h, self._stream(), name.encode(), C.c_void_p(out.data_ptr())), "kk_mimi_debug_fetch")
+        return out

@@ -1,0 +1,79 @@
+"""Mimi.decode through the C ABI (kk_mimi_*) against the CPU oracle (oracle/mimi_oracle.py) on identical synthetic weights and
+codes.  fp32 path: every stage within 2e-4 of its max, pcm within 1e-3 (BASELINE north_star tolerance)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+import mimi_oracle as M  # noqa: E402
+import mlx_audio_amd.params as P  # noqa: E402
+from _util import err_stats, report  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ["quantized", "upsampled", "transformer", "layer0", "layer1", "layer2", "layer3"]
+
+
+def _pair(cfg, seed, B, Nf, tag):
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+
+    w = P.mimi_synth_checkpoint(cfg, seed)
+    rng = np.random.default_rng(seed + 100)
+    codes = rng.integers(0, cfg["bins"], (B, cfg["nq"], Nf))
+    codes[0, :, 0] = 0  # a never-used code-book entry (cluster_usage = 0 -> the 1e-5 floor)
+    ref, inter = M.MimiOracle(w, cfg).decode(codes, return_inter=True)
+    model = Mimi(MimiConfig.from_dict(cfg), w)
+    pcm = model.decode(torch.tensor(codes))
+    torch.cuda.synchronize()
+    got = pcm.cpu().numpy()
+    assert got.shape == ref.shape == (B, 1, 1920 * Nf)
+    worst = {}
+    for name in STAGES:
+        g = model.debug_fetch(name).cpu().numpy()  # [B][rows][C]
+        r = np.transpose(inter[name], (0, 2, 1))
+        e = err_stats(g, r)
+        report(f"mimi/{tag}/{name}", **e)
+        worst[name] = e["rel_max"]
+    e = err_stats(got, ref)
+    report(f"mimi/{tag}/pcm", **e)
+    return e, worst, model, codes, got
+
+
+def test_mimi_tiny_decode_matches_oracle():
+    e, worst, model, codes, got = _pair(P.mimi_tiny_config(), 3, 3, 11, "tiny")
+    for k, v in worst.items():
+        assert v < 2e-4, (k, v)
+    assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+    # batch items are independent: item 1 alone gives the same bits
+    one = model.decode(torch.tensor(codes[1:2])).cpu().numpy()
+    np.testing.assert_array_equal(one[0], got[1])
+
+
+def test_mimi_202407_decode_matches_oracle():
+    """The real configuration (57 M decode-side parameters), 20 frames = 1.6 s of audio, batch 2."""
+    e, worst, _, _, _ = _pair(P.mimi_config(32), 4, 2, 20, "202407")
+    for k, v in worst.items():
+        assert v < 2e-4, (k, v)
+    assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+
+
+def test_mimi_reference_shape_known_answer_on_gpu():
+    """mlx_audio/codec/tests/test_mimi.py: codes [1, 32, 63] -> pcm [1, 1, 120960]."""
+    from mlx_audio_amd.mimi import Mimi, mimi_202407
+
+    cfg = P.mimi_config(32)
+    model = Mimi(mimi_202407(32), P.mimi_synth_checkpoint(cfg, 0))
+    pcm = model.decode(torch.zeros((1, 32, 63), dtype=torch.int64))
+    torch.cuda.synchronize()
+    assert tuple(pcm.shape) == (1, 1, 120_960) and bool(torch.isfinite(pcm).all())
+    assert model.sample_rate == 24000 and model.frame_rate == 12.5
+    with pytest.raises(ValueError):
+        model.decode(torch.zeros((1, 31, 5), dtype=torch.int64))
