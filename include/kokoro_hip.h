@@ -187,7 +187,7 @@ typedef struct kk_mimi_config {
   int32_t n_ratios, ratios[8];
   int32_t ksize, residual_ksize, last_ksize, upsample_stride, compress;
   float rope_base;
-  int32_t compute_dtype; /* KK_F32 (round 1) */
+  int32_t compute_dtype; /* KK_F32: parity path (generic fp32 kernels); KK_BF16: bf16 activations, variant-4 MFMA convolutions */
 } kk_mimi_config;
 
 int kk_mimi_create(const kk_mimi_config* cfg, kk_mimi** out);

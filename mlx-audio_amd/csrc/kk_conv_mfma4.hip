@@ -214,7 +214,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           // padding rows / pad channels stay exactly zero.  32-bit integer ops only: touching the slab registers as bf16
           // ELEMENTS makes hipcc split them into 16-bit pieces right at the loads (and wait for the loads there)
           unsigned wq[4] = {xreg[i].x & msk & cm[0], xreg[i].y & msk & cm[1], xreg[i].z & msk & cm[2], xreg[i].w & msk & cm[3]};
-          if (a.in_slope != 1.0f) {
+          if (NRM == 0 && a.in_act == KK_ACT_ELU) {  // nn.elu: where(x > 0, x, exp(x) - 1); elu(0) = 0 keeps the padding zero
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float lo = __uint_as_float(wq[k] << 16), hi = __uint_as_float(wq[k] & 0xFFFF0000u);
+              lo = lo > 0.f ? lo : __expf(lo) - 1.0f;
+              hi = hi > 0.f ? hi : __expf(hi) - 1.0f;
+              const bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
+              wq[k] = __builtin_bit_cast(unsigned, pk);
+            }
+          } else if (a.in_slope != 1.0f) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               float lo = __uint_as_float(wq[k] << 16), hi = __uint_as_float(wq[k] & 0xFFFF0000u);
@@ -417,6 +426,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           for (int k = 0; k < 4; ++k) {
             v[k].x = gelu_exact(v[k].x);
             v[k].y = gelu_exact(v[k].y);
+          }
+        } else if (NRM == 0 && a.act == KK_ACT_GELU_TANH) {  // nn.gelu_approx (plain variant only: keeps the fused variants' registers)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k].x = 0.5f * v[k].x * (1.0f + tanhf(0.7978845608028654f * (v[k].x + 0.044715f * (v[k].x * v[k].x * v[k].x))));
+            v[k].y = 0.5f * v[k].y * (1.0f + tanhf(0.7978845608028654f * (v[k].y + 0.044715f * (v[k].y * v[k].y * v[k].y))));
           }
         }
         if (rb) {

@@ -28,6 +28,7 @@ struct KKMfmaArgs {
   float in_slope, scale;
   int accumulate, act;
   float act_slope;
+  int in_act;  // variant 4 only: KK_ACT_ELU = elu(x, 1) applied to the input while it is staged (Mimi SEANet); 0 = leaky-relu(in_slope)
   int dbg;  // timing experiments only (KK_MFMA_DBG): bit0 skip W reloads, bit1 skip X reloads
   // fused input transform (AdaIN apply + activation while staging X):  y = act(x * nrm_a[b][c] + nrm_b[b][c])
   const float* nrm_a;  // [B][nrm_stride], zero for pad channels; null = no transform

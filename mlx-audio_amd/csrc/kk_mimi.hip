@@ -26,12 +26,13 @@
 
 namespace {
 
-struct PackedConv {  // generic-kernel pack [K][Cin][ldw] fp32 (+ bias)
-  size_t w_off = 0, b_off = 0;
-  bool has_bias = false;
-  int Cin = 0, Cout = 0, K = 0, ldw = 0;
+struct PackedConv {  // generic-kernel pack [K][Cin][ldw] fp32 (+ bias); bf16 mode: MFMA fragment-order pack as well
+  size_t w_off = 0, b_off = 0, wf_off = 0;
+  bool has_bias = false, mfma = false;
+  int Cin = 0, Cout = 0, K = 0, ldw = 0, CinP = 0, CoutP = 0;
   const float* w = nullptr;
-  const float* b = nullptr;
+  const float* b = nullptr;  // [CoutP] when mfma (zero padded), else [Cout]
+  const bf16_t* wf = nullptr;
 };
 struct PackedVec {
   size_t off = 0;
@@ -47,10 +48,10 @@ struct SeaLayer {
   int ratio = 1;
 };
 struct DebugBuf {
-  const float* p;
+  const void* p;
   int rows, C, ld;
   long long bs;
-  int B;
+  int B, dtype;
 };
 
 }  // namespace
@@ -61,6 +62,7 @@ struct kk_mimi {
   std::vector<float> pack;
   float* dev = nullptr;
   bool finalized = false;
+  int adt = KK_F32;  // activation dtype: KK_F32 (parity path) or KK_BF16 (MFMA convolutions, bf16 activations)
   PackedVec codebooks;  // [nq][bins][qdim]
   PackedVec inv_freq;   // [32]
   PackedVec up_w;       // [2*stride][dim]
@@ -75,14 +77,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------- kernels
 // one workgroup per (frame, item): column c of the first code book's row, and of the sum of the other rows in ascending
 // code-book order (the reference's accumulation order, quantization.py:97-101)
-__global__ __launch_bounds__(256) void rvq_sum_kernel(const int* codes, const float* cb, int nq, int bins, int qdim, int Nf, float* q_first,
-                                                      float* q_rest) {
+template <typename T>
+__global__ __launch_bounds__(256) void rvq_sum_kernel(const int* codes, const float* cb, int nq, int bins, int qdim, int Nf, int ld, T* q_first,
+                                                      T* q_rest) {
   const int t = blockIdx.x, b = blockIdx.y;
   for (int c = threadIdx.x; c < qdim; c += blockDim.x) {
     const int* cd = codes + (long long)b * nq * Nf + t;
     int id = cd[0];
     id = id < 0 ? 0 : (id >= bins ? bins - 1 : id);
-    q_first[((long long)b * Nf + t) * qdim + c] = cb[(long long)id * qdim + c];
+    kk_st(q_first + ((long long)b * Nf + t) * ld + c, cb[(long long)id * qdim + c]);
     float s = 0.f;
     for (int i = 1; i < nq; ++i) {
       int idi = cd[(long long)i * Nf];
@@ -90,41 +93,50 @@ __global__ __launch_bounds__(256) void rvq_sum_kernel(const int* codes, const fl
       const float e = cb[((long long)i * bins + idi) * qdim + c];
       s = i == 1 ? e : s + e;
     }
-    q_rest[((long long)b * Nf + t) * qdim + c] = s;
+    kk_st(q_rest + ((long long)b * Nf + t) * ld + c, s);
   }
 }
 
 // depth-wise transposed conv, kernel 2*s, stride s, causal (last s outputs dropped): output row p = s*t + j gets
 // x[t] w[j] + x[t-1] w[j + s]
-__global__ __launch_bounds__(256) void upsample_dw_kernel(const float* x, const float* w, int C, int Lin, int s, float* out) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_dw_kernel(const T* x, const float* w, int C, int ld, int Lin, int s, T* out) {
   const int p = blockIdx.x, b = blockIdx.y;
   const int tt = p / s, j = p - tt * s;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float v = x[((long long)b * Lin + tt) * C + c] * w[(long long)j * C + c];
-    if (tt > 0) v += x[((long long)b * Lin + tt - 1) * C + c] * w[(long long)(j + s) * C + c];
-    out[((long long)b * Lin * s + p) * C + c] = v;
+    float v = kk_ld(x + ((long long)b * Lin + tt) * ld + c) * w[(long long)j * C + c];
+    if (tt > 0) v += kk_ld(x + ((long long)b * Lin + tt - 1) * ld + c) * w[(long long)(j + s) * C + c];
+    kk_st(out + ((long long)b * Lin * s + p) * ld + c, v);
   }
 }
 
 // nn.RoPE(traditional): pairs (2i, 2i+1) of every q and k head rotated by pos * inv_freq[i]; qkv [B][T][3*D] in place
-__global__ __launch_bounds__(256) void rope_kernel(float* qkv, const float* inv_freq, int T, int D, int hd) {
+template <typename TT>
+__global__ __launch_bounds__(256) void rope_kernel(TT* qkv, const float* inv_freq, int T, int D, int ld, int hd) {
   const int t = blockIdx.x, b = blockIdx.y;
-  float* row = qkv + ((long long)b * T + t) * 3 * D;
+  TT* row = qkv + ((long long)b * T + t) * ld;
   const int half = hd / 2, npairs = D / 2;
   for (int e = threadIdx.x; e < 2 * npairs; e += blockDim.x) {
     const int which = e / npairs, pr = e - which * npairs;  // q (0) or k (1)
     const int h = pr / half, i = pr - h * half;
     const float ang = (float)t * inv_freq[i];
     const float c = cosf(ang), s = sinf(ang);
-    float* p2 = row + which * D + h * hd + 2 * i;
-    const float x0 = p2[0], x1 = p2[1];
-    p2[0] = x0 * c - x1 * s;
-    p2[1] = x0 * s + x1 * c;
+    TT* p2 = row + which * D + h * hd + 2 * i;
+    const float x0 = kk_ld(p2), x1 = kk_ld(p2 + 1);
+    kk_st(p2, x0 * c - x1 * s);
+    kk_st(p2 + 1, x0 * s + x1 * c);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------- host
 int rup(int v, int m) { return (v + m - 1) / m * m; }
+uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
 
 struct Packer {
   kk_mimi* m;
@@ -170,12 +182,32 @@ struct Packer {
           if (row_scale) v *= (*row_scale)[o];
           dst[((size_t)k * I + i) * c.ldw + o] = v;
         }
-    if (!bname.empty()) {
-      const std::vector<float>* b = get(bname, (size_t)O);
-      if (!b) return c;
+    // bf16 mode: the same weights in MFMA fragment order for the variant-4 kernel (needs Cout % 8 == 0, >= 16 channels both ways)
+    c.mfma = m->adt == KK_BF16 && O % 8 == 0 && O >= 16 && I >= 16;
+    if (c.mfma) {
+      c.CinP = rup(I, 64);
+      c.CoutP = rup(O, 128);
+      const size_t nel = (size_t)K * c.CoutP * c.CinP;
+      c.wf_off = alloc((nel + 1) / 2);
+      w = get(wname, (size_t)O * K * I);  // (alloc may have moved nothing here, but keep the pointer fresh)
+      uint16_t* dfr = (uint16_t*)&m->pack[c.wf_off];
+      for (int o = 0; o < O; ++o)
+        for (int k = 0; k < K; ++k)
+          for (int i = 0; i < I; ++i) {
+            float v = (*w)[((size_t)o * K + k) * I + i];
+            if (row_scale) v *= (*row_scale)[o];
+            dfr[kk_mfma4_pack_index(k, o, i, c.CoutP, c.CinP)] = f32_to_bf16_rne(v);
+          }
+    }
+    const int nb = c.mfma ? c.CoutP : O;
+    if (!bname.empty() || c.mfma) {
       c.has_bias = true;
-      c.b_off = alloc(O);
-      memcpy(&m->pack[c.b_off], b->data(), (size_t)O * 4);
+      c.b_off = alloc(nb);  // zero filled
+      if (!bname.empty()) {
+        const std::vector<float>* b = get(bname, (size_t)O);
+        if (!b) return c;
+        memcpy(&m->pack[c.b_off], b->data(), (size_t)O * 4);
+      }
     }
     return c;
   }
@@ -184,8 +216,15 @@ struct Packer {
 void resolve(kk_mimi* m, PackedConv& c) {
   c.w = m->dev + c.w_off;
   c.b = c.has_bias ? m->dev + c.b_off : nullptr;
+  c.wf = c.mfma ? (const bf16_t*)(m->dev + c.wf_off) : nullptr;
 }
 void resolve(kk_mimi* m, PackedVec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
+
+struct Act {  // an activation tensor [B][rows][ld], C valid channels
+  void* p = nullptr;
+  int rows = 0, C = 0, ld = 0, dtype = KK_F32;
+  long long bs() const { return (long long)rows * ld; }
+};
 
 struct Run {
   kk_mimi* m;
@@ -194,39 +233,64 @@ struct Run {
   char* base;
   size_t cap, used;
   bool dry;
-  float* f32(size_t n) {
+  bool oom = false;
+  void* raw(size_t bytes) {
     const size_t off = (used + 255) & ~(size_t)255;
-    used = off + n * 4;
+    used = off + bytes;
     if (dry) return nullptr;
-    return used <= cap ? (float*)(base + off) : nullptr;
+    if (used > cap) { oom = true; return nullptr; }
+    return base + off;
   }
-  // conv / transposed conv / linear on [B][L][C] fp32 buffers (pitch = channel count)
-  int conv(const PackedConv& w, const float* x, int Lin, float* out, int Lout, int pad, int dil, bool transposed, int stride, int in_act,
-           int act, const float* res, int accumulate) {
+  // bf16 tensors get a pitch that is a multiple of 64 so any of them can feed the MFMA kernel (pad channels are never read as
+  // data: the kernel masks channels >= Cin)
+  Act act(int rows, int C, int dtype = -1) {
+    Act t;
+    t.dtype = dtype < 0 ? m->adt : dtype;
+    t.rows = rows; t.C = C;
+    t.ld = t.dtype == KK_BF16 ? rup(C, 64) : C;
+    t.p = raw((size_t)B * rows * t.ld * (t.dtype == KK_BF16 ? 2 : 4));
+    return t;
+  }
+  // conv / transposed conv / linear
+  int conv(const PackedConv& w, const Act& x, const Act& out, int pad, int dil, bool transposed, int stride, int in_act, int act_,
+           const Act* res, int accumulate) {
     if (dry) return 0;
+    const int Lin = x.rows, Lout = out.rows;
+    if (w.mfma && x.dtype == KK_BF16 && out.dtype == KK_BF16 && x.ld >= w.CinP && kk_mfma_eligible(w.Cin, w.Cout, w.K, transposed ? KK_CONVT : KK_CONV, stride, dil)) {
+      KKMfmaArgs g;
+      memset(&g, 0, sizeof g);
+      g.x = (const bf16_t*)x.p; g.xbs = x.bs(); g.ldx = x.ld; g.wf = w.wf; g.CinP = w.CinP; g.Cin = w.Cin; g.CoutP = w.CoutP; g.bias = w.b;
+      g.out = out.p; g.obs = out.bs(); g.ldo = out.ld;
+      if (res) { g.res = res->p; g.rbs = res->bs(); g.ldr = res->ld; }
+      g.Cout = w.Cout; g.Kw = w.K; g.mode = transposed ? KK_CONVT : KK_CONV; g.stride = stride; g.pad = pad; g.dil = dil;
+      g.Q = transposed ? kk_cdiv(Lout, stride) : Lout; g.Lo_rows = Lout;
+      g.lin = KKLen{nullptr, 0, Lin}; g.lout = KKLen{nullptr, 0, Lout};
+      g.in_slope = 1.f; g.scale = 1.f; g.accumulate = accumulate; g.act = act_; g.in_act = in_act;
+      return kk_launch_conv_mfma4(g, B, KK_BF16, st);
+    }
     KKConvArgs a;
     memset(&a, 0, sizeof a);
-    a.x = x; a.xbs = (long long)Lin * w.Cin; a.ldx = w.Cin;
+    a.x = x.p; a.xbs = x.bs(); a.ldx = x.ld;
     a.w = w.w; a.ldw = w.ldw; a.bias = w.b;
-    a.out = out; a.obs = (long long)Lout * w.Cout; a.ldo = w.Cout;
-    if (res) { a.res = res; a.rbs = a.obs; a.ldr = w.Cout; }
+    a.out = out.p; a.obs = out.bs(); a.ldo = out.ld;
+    if (res) { a.res = res->p; a.rbs = res->bs(); a.ldr = res->ld; }
     a.Cin = w.Cin; a.Cout = w.Cout; a.Kw = w.K;
     a.mode = transposed ? KK_CONVT : KK_CONV; a.stride = stride; a.pad = pad; a.dil = dil;
     a.Q = transposed ? kk_cdiv(Lout, stride) : Lout; a.Lo_rows = Lout;
     a.lin = KKLen{nullptr, 0, Lin}; a.lout = KKLen{nullptr, 0, Lout};
-    a.in_slope = 1.f; a.scale = 1.f; a.accumulate = accumulate; a.act = act; a.in_act = in_act;
-    return kk_launch_conv_generic(a, B, KK_F32, KK_F32, st);
+    a.in_slope = 1.f; a.scale = 1.f; a.accumulate = accumulate; a.act = act_; a.in_act = in_act;
+    return kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
   }
-  int layernorm(const float* x, float* out, int C, int L, const float* w, const float* b) {
+  int layernorm(const Act& x, const Act& out, const float* w, const float* b) {
     if (dry) return 0;
     KKLnArgs a;
     memset(&a, 0, sizeof a);
-    a.x = x; a.xbs = (long long)L * C; a.ldx = C; a.out = out; a.obs = a.xbs; a.ldo = C; a.C = C; a.Lmax = L;
-    a.len = KKLen{nullptr, 0, L}; a.w = w; a.bias = b; a.eps = 1e-5f; a.act = KK_ACT_NONE;
-    return kk_launch_layernorm(a, B, KK_F32, st);
+    a.x = x.p; a.xbs = x.bs(); a.ldx = x.ld; a.out = out.p; a.obs = out.bs(); a.ldo = out.ld; a.C = x.C; a.Lmax = x.rows;
+    a.len = KKLen{nullptr, 0, x.rows}; a.w = w; a.bias = b; a.eps = 1e-5f; a.act = KK_ACT_NONE;
+    return kk_launch_layernorm(a, B, x.dtype, st);
   }
-  void note(const char* name, const float* p, int rows, int C) {
-    if (!dry) m->dbg[name] = DebugBuf{p, rows, C, C, (long long)rows * C, B};
+  void note(const char* name, const Act& t) {
+    if (!dry) m->dbg[name] = DebugBuf{t.p, t.rows, t.C, t.ld, t.bs(), B, t.dtype};
   }
 };
 
@@ -240,72 +304,74 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
   kk_mimi* m = r.m;
   const kk_mimi_config& c = m->cfg;
   const int B = r.B, D = c.dim, Q = c.qdim, T = Nf * c.upsample_stride;
+  const bool bf = m->adt == KK_BF16;
   // ---- split RVQ decode
-  float* q1 = r.f32((size_t)B * Nf * Q);
-  float* q2 = r.f32((size_t)B * Nf * Q);
-  float* x0 = r.f32((size_t)B * Nf * D);
-  float* x = r.f32((size_t)B * T * D);
-  if (!r.dry && (!q1 || !q2 || !x0 || !x)) return kk_fail("kk_mimi_decode: workspace too small");
+  Act q1 = r.act(Nf, Q), q2 = r.act(Nf, Q), x0 = r.act(Nf, D), xu = r.act(T, D), x = r.act(T, D);
+  Act n = r.act(T, D), qkv = r.act(T, 3 * D), att = r.act(T, D), hbuf = r.act(T, c.dim_feedforward);
+  if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
   if (!r.dry) {
-    hipLaunchKernelGGL(rvq_sum_kernel, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1, q2);
+    if (bf) {
+      hipLaunchKernelGGL(rvq_sum_kernel<bf16_t>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (bf16_t*)q1.p, (bf16_t*)q2.p);
+    } else {
+      hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (float*)q1.p, (float*)q2.p);
+    }
     KK_CHECK_LAUNCH();
   }
-  MM_TRY(r.conv(m->proj_first, q1, Nf, x0, Nf, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
-  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, Nf, x0, Nf, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
-  r.note("quantized", x0, Nf, D);
-  float* xu = r.f32((size_t)B * T * D);  // kept for the debug hook: the transformer updates x in place
+  MM_TRY(r.conv(m->proj_first, q1, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
+  r.note("quantized", x0);
   if (!r.dry) {
-    if (!xu) return kk_fail("kk_mimi_decode: workspace too small");
-    hipLaunchKernelGGL(upsample_dw_kernel, dim3(T, B), dim3(256), 0, r.st, x0, m->up_w.p, D, Nf, c.upsample_stride, xu);
+    if (bf)
+      hipLaunchKernelGGL(upsample_dw_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (const bf16_t*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (bf16_t*)xu.p);
+    else
+      hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (const float*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (float*)xu.p);
     KK_CHECK_LAUNCH();
-    if (hipMemcpyAsync(x, xu, (size_t)B * T * D * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_decode: copy failed");
+    // xu is kept for the debug hook: the transformer updates x in place
+    if (hipMemcpyAsync(x.p, xu.p, (size_t)B * T * xu.ld * (bf ? 2 : 4), hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_decode: copy failed");
   }
-  r.note("upsampled", xu, T, D);
+  r.note("upsampled", xu);
   // ---- transformer
-  float* n = r.f32((size_t)B * T * D);
-  float* qkv = r.f32((size_t)B * T * 3 * D);
-  float* att = r.f32((size_t)B * T * D);
-  float* hbuf = r.f32((size_t)B * T * c.dim_feedforward);
-  if (!r.dry && (!n || !qkv || !att || !hbuf)) return kk_fail("kk_mimi_decode: workspace too small");
   for (int l = 0; l < c.num_layers; ++l) {
     const MimiLayer& L = m->layers[l];
-    MM_TRY(r.layernorm(x, n, D, T, L.n1w.p, L.n1b.p));
-    MM_TRY(r.conv(L.in_proj, n, T, qkv, T, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.layernorm(x, n, L.n1w.p, L.n1b.p));
+    MM_TRY(r.conv(L.in_proj, n, qkv, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
     if (!r.dry) {
-      hipLaunchKernelGGL(rope_kernel, dim3(T, B), dim3(256), 0, r.st, qkv, m->inv_freq.p, T, D, D / c.num_heads);
+      if (bf)
+        hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (bf16_t*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
+      else
+        hipLaunchKernelGGL(rope_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (float*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
       KK_CHECK_LAUNCH();
       KKAttnArgs a;
       memset(&a, 0, sizeof a);
-      a.qkv = qkv; a.bs = (long long)T * 3 * D; a.ld = 3 * D; a.out = att; a.obs = (long long)T * D; a.ldo = D;
+      a.qkv = qkv.p; a.bs = qkv.bs(); a.ld = qkv.ld; a.out = att.p; a.obs = att.bs(); a.ldo = att.ld;
       a.heads = c.num_heads; a.hs = D; a.Tmax = T; a.len = KKLen{nullptr, 0, T}; a.scale = 1.0f / sqrtf((float)(D / c.num_heads));
-      MM_TRY(kk_launch_attention(a, B, KK_F32, r.st));
+      MM_TRY(kk_launch_attention(a, B, qkv.dtype, r.st));
     }
-    MM_TRY(r.conv(L.out_proj, att, T, x, T, 0, 1, false, 1, 0, KK_ACT_NONE, x, 0));  // x += ls1 * (W att)
-    MM_TRY(r.layernorm(x, n, D, T, L.n2w.p, L.n2b.p));
-    MM_TRY(r.conv(L.lin1, n, T, hbuf, T, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
-    MM_TRY(r.conv(L.lin2, hbuf, T, x, T, 0, 1, false, 1, 0, KK_ACT_NONE, x, 0));     // x += ls2 * (W2 gelu(W1 n))
+    MM_TRY(r.conv(L.out_proj, att, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));  // x += ls1 * (W att)
+    MM_TRY(r.layernorm(x, n, L.n2w.p, L.n2b.p));
+    MM_TRY(r.conv(L.lin1, n, hbuf, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
+    MM_TRY(r.conv(L.lin2, hbuf, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));     // x += ls2 * (W2 gelu(W1 n))
   }
-  r.note("transformer", x, T, D);
+  r.note("transformer", x);
   // ---- SEANet decoder
-  int Lc = T, Cc = m->init_conv.Cout;
-  float* y = r.f32((size_t)B * Lc * Cc);
-  if (!r.dry && !y) return kk_fail("kk_mimi_decode: workspace too small");
-  MM_TRY(r.conv(m->init_conv, x, T, y, T, (c.ksize - 1), 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  Act y = r.act(T, m->init_conv.Cout);
+  if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
+  MM_TRY(r.conv(m->init_conv, x, y, (c.ksize - 1), 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
   static const char* lname[8] = {"layer0", "layer1", "layer2", "layer3", "layer4", "layer5", "layer6", "layer7"};
   for (size_t l = 0; l < m->sea.size(); ++l) {
     const SeaLayer& S = m->sea[l];
-    const int Lo = Lc * S.ratio, Co = S.up.Cout;
-    float* u = r.f32((size_t)B * Lo * Co);
-    float* hb = r.f32((size_t)B * Lo * S.b0.Cout);
-    float* o = r.f32((size_t)B * Lo * Co);
-    if (!r.dry && (!u || !hb || !o)) return kk_fail("kk_mimi_decode: workspace too small");
-    MM_TRY(r.conv(S.up, y, Lc, u, Lo, 0, 1, true, S.ratio, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
-    MM_TRY(r.conv(S.b0, u, Lo, hb, Lo, (c.residual_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
-    MM_TRY(r.conv(S.b1, hb, Lo, o, Lo, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, u, 0));
-    r.note(l < 8 ? lname[l] : "layerN", o, Lo, Co);
-    y = o; Lc = Lo; Cc = Co;
+    const int Lo = y.rows * S.ratio, Co = S.up.Cout;
+    Act u = r.act(Lo, Co), hb = r.act(Lo, S.b0.Cout), o = r.act(Lo, Co);
+    if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
+    MM_TRY(r.conv(S.up, y, u, 0, 1, true, S.ratio, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.conv(S.b0, u, hb, (c.residual_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.conv(S.b1, hb, o, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, &u, 0));
+    r.note(l < 8 ? lname[l] : "layerN", o);
+    y = o;
   }
-  MM_TRY(r.conv(m->final_conv, y, Lc, pcm, Lc, (c.last_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  Act out;
+  out.p = pcm; out.rows = y.rows; out.C = 1; out.ld = 1; out.dtype = KK_F32;
+  MM_TRY(r.conv(m->final_conv, y, out, (c.last_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
   return 0;
 }
 
@@ -325,6 +391,7 @@ extern "C" int kk_mimi_create(const kk_mimi_config* cfg, kk_mimi** out) {
   MM_TRY(check_cfg(*cfg));
   kk_mimi* m = new kk_mimi();
   m->cfg = *cfg;
+  m->adt = cfg->compute_dtype == KK_BF16 ? KK_BF16 : KK_F32;
   *out = m;
   return 0;
 }
@@ -431,7 +498,7 @@ extern "C" int64_t kk_mimi_samples_per_frame(const kk_mimi* m) {
 
 extern "C" size_t kk_mimi_workspace_bytes(kk_mimi* m, int B, int Nf) {
   if (!m || !m->finalized || B <= 0 || Nf <= 0) return 0;
-  Run r{m, nullptr, B, nullptr, 0, 0, true};
+  Run r{m, nullptr, B, nullptr, 0, 0, true, false};
   if (run_decode(r, Nf, nullptr, nullptr) != 0) return 0;
   return r.used + 256;
 }
@@ -442,7 +509,7 @@ extern "C" int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int
   if (B <= 0 || Nf <= 0 || !codes || !workspace || !pcm_out) return kk_fail("kk_mimi_decode: bad argument");
   if (workspace_bytes < kk_mimi_workspace_bytes(m, B, Nf)) return kk_fail("kk_mimi_decode: workspace too small");
   m->dbg.clear();
-  Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false};
+  Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   return run_decode(r, Nf, codes, pcm_out);
 }
 
@@ -460,7 +527,7 @@ extern "C" int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, f
   auto it = m->dbg.find(name);
   if (it == m->dbg.end()) return kk_fail("kk_mimi_debug_fetch: unknown stage");
   const DebugBuf& d = it->second;
-  if (hipMemcpyAsync(dst, d.p, (size_t)d.B * d.rows * d.C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-    return kk_fail("kk_mimi_debug_fetch: copy failed");
+  // any dtype / pitch -> dense fp32 [B][rows][C]
+  if (kk_launch_convert(d.p, d.dtype, d.bs, d.ld, dst, KK_F32, (long long)d.rows * d.C, d.C, d.C, d.rows, d.B, (hipStream_t)stream) != 0) return -1;
   return 0;
 }

@@ -46,7 +46,7 @@ def mimi_202407(num_codebooks: int) -> MimiConfig:
 
 
 class Mimi:
-    def __init__(self, cfg: MimiConfig, weights: Dict[str, np.ndarray] | None = None, device: str = "cuda:0"):
+    def __init__(self, cfg: MimiConfig, weights: Dict[str, np.ndarray] | None = None, device: str = "cuda:0", compute_dtype: str = "float32"):
         self.cfg = cfg
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -60,7 +60,9 @@ class Mimi:
         for i, r in enumerate(cfg.ratios):
             kc.ratios[i] = int(r)
         kc.rope_base = float(cfg.rope_base)
-        kc.compute_dtype = _lib.KK_F32
+        if compute_dtype not in ("float32", "bfloat16"):
+            raise ValueError("compute_dtype must be float32 or bfloat16")
+        kc.compute_dtype = _lib.KK_BF16 if compute_dtype == "bfloat16" else _lib.KK_F32
         h = C.c_void_p()
         check(self.lib.kk_mimi_create(C.byref(kc), C.byref(h)), "kk_mimi_create")
         self._h = h

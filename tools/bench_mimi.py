@@ -19,10 +19,11 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--frames", type=int, default=125)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--no-cpu-baseline", action="store_true")
+ap.add_argument("--dtype", default="bfloat16", choices=["float32", "bfloat16"])
 a = ap.parse_args()
 cfg = P.mimi_config(32)
 w = P.mimi_synth_checkpoint(cfg, 0)
-model = Mimi(mimi_202407(32), w)
+model = Mimi(mimi_202407(32), w, compute_dtype=a.dtype)
 codes = torch.tensor(np.random.default_rng(0).integers(0, 2048, (a.batch, 32, a.frames)), device="cuda", dtype=torch.int32)
 for _ in range(2):
     model.decode(codes)
@@ -33,8 +34,8 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 audio_s = a.batch * a.frames / 12.5
-out = {"metric": "audio-sec/sec (xRT), Mimi.decode mimi_202407 fp32", "value": audio_s / dt, "ms_per_decode": dt * 1e3, "batch": a.batch,
-       "frames": a.frames, "audio_s_per_item": a.frames / 12.5, "dtype": "f32", "data": "synthetic (random-init decode-side weights, random codes)"}
+out = {"metric": "audio-sec/sec (xRT), Mimi.decode mimi_202407", "value": audio_s / dt, "ms_per_decode": dt * 1e3, "batch": a.batch,
+       "frames": a.frames, "audio_s_per_item": a.frames / 12.5, "dtype": "bf16" if a.dtype == "bfloat16" else "f32", "data": "synthetic (random-init decode-side weights, random codes)"}
 if not a.no_cpu_baseline:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mimi_oracle as M
