@@ -128,6 +128,107 @@ __global__ __launch_bounds__(256) void rope_kernel(TT* qkv, const float* inv_fre
   }
 }
 
+// SEANet's last conv (seanet.py:258-268): Cout = 1, so it is a dot product per sample -- HBM-bound (one read of x), not a GEMM.
+// out[b][t] = bias + sum_k sum_c elu(x[b][t - pad + k][c]) w[k][c]   (rows before 0 are zero padding); w is the generic pack
+// [K][Cin][ldw] read at column 0.  One lane per output sample; weights (K * Cin floats) sit in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const T* x, int ld, int L, int Cin, int K, int pad, const float* w, int ldw,
+                                                         const float* bias, int elu, float* out) {
+  extern __shared__ float wsm[];
+  for (int e = threadIdx.x; e < K * Cin; e += 256) wsm[e] = w[(long long)e * ldw];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  float acc = bias ? bias[0] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const long long r = t - pad + k;
+    if (r < 0 || r >= L) continue;
+    const T* xr = x + ((long long)b * L + r) * ld;
+    const float* wk = wsm + k * Cin;
+    if (sizeof(T) == 2 && (Cin & 7) == 0 && (ld & 7) == 0) {  // bf16 rows as 16-byte vectors
+      for (int c = 0; c < Cin; c += 8) {
+        const uint4 q = *(const uint4*)(xr + c);
+        const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = __uint_as_float(wd[j] << 16), hi = __uint_as_float(wd[j] & 0xFFFF0000u);
+          if (elu) {
+            lo = lo > 0.f ? lo : __expf(lo) - 1.0f;
+            hi = hi > 0.f ? hi : __expf(hi) - 1.0f;
+          }
+          acc = __builtin_fmaf(lo, wk[c + 2 * j], acc);
+          acc = __builtin_fmaf(hi, wk[c + 2 * j + 1], acc);
+        }
+      }
+    } else {
+      for (int c = 0; c < Cin; ++c) {
+        float v = kk_ld(xr + c);
+        if (elu) v = v > 0.f ? v : expf(v) - 1.0f;
+        acc = __builtin_fmaf(v, wk[c], acc);
+      }
+    }
+  }
+  out[(long long)b * L + t] = acc;
+}
+
+// bf16 form of the same conv: the workgroup's 256 + K - 1 input rows are staged ONCE in LDS with coalesced 16-byte loads (ELU applied
+// once per element, rows pitched 144 B so the per-lane row reads below are conflict-free), then one lane per output sample.
+constexpr int C1_LD = 72;  // bf16 elements per LDS row (64 channels + 8 pad)
+__global__ __launch_bounds__(256) void conv_cout1_bf16_kernel(const bf16_t* x, int ld, int L, int Cin, int K, int pad, const float* w, int ldw,
+                                                              const float* bias, int elu, float* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c1sm[];
+  bf16_t* xs = (bf16_t*)c1sm;                                     // [256 + K - 1][72]
+  float* wsm = (float*)(c1sm + (size_t)(256 + K - 1) * C1_LD * 2);  // [K][Cin]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const long long t0 = (long long)blockIdx.x * 256;
+  for (int e = tid; e < K * Cin; e += 256) wsm[e] = w[(long long)e * ldw];
+  const int cpr = Cin / 8, nrow = 256 + K - 1;
+  for (int e = tid; e < nrow * cpr; e += 256) {
+    const int rr = e / cpr, ch = e - rr * cpr;
+    const long long r = t0 - pad + rr;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (r >= 0 && r < L) {
+      q = *(const uint4*)(x + ((long long)b * L + r) * ld + ch * 8);
+      if (elu) {
+        unsigned wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = __uint_as_float(wd[j] << 16), hi = __uint_as_float(wd[j] & 0xFFFF0000u);
+          lo = lo > 0.f ? lo : __expf(lo) - 1.0f;
+          hi = hi > 0.f ? hi : __expf(hi) - 1.0f;
+          typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+          const b2 pk = {(bf16_t)lo, (bf16_t)hi};
+          wd[j] = __builtin_bit_cast(unsigned, pk);
+        }
+        q = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+    }
+    *(uint4*)(xs + rr * C1_LD + ch * 8) = q;
+  }
+  __syncthreads();
+  const long long t = t0 + tid;
+  if (t >= L) return;
+  float acc = bias ? bias[0] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const bf16_t* xr = xs + (tid + k) * C1_LD;
+    const float* wk = wsm + k * Cin;
+    for (int c = 0; c < Cin; c += 8) {
+      const uint4 q = *(const uint4*)(xr + c);
+      const float4 wa = *(const float4*)(wk + c), wb = *(const float4*)(wk + c + 4);
+      acc = __builtin_fmaf(__uint_as_float(q.x << 16), wa.x, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.x & 0xFFFF0000u), wa.y, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.y << 16), wa.z, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.y & 0xFFFF0000u), wa.w, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.z << 16), wb.x, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.z & 0xFFFF0000u), wb.y, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.w << 16), wb.z, acc);
+      acc = __builtin_fmaf(__uint_as_float(q.w & 0xFFFF0000u), wb.w, acc);
+    }
+  }
+  out[(long long)b * L + t] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 uint16_t f32_to_bf16_rne(float f) {
@@ -371,6 +472,22 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
   }
   Act out;
   out.p = pcm; out.rows = y.rows; out.C = 1; out.ld = 1; out.dtype = KK_F32;
+  if (m->final_conv.Cout == 1 && (size_t)m->final_conv.K * m->final_conv.Cin * 4 <= 32768) {
+    if (!r.dry) {
+      const PackedConv& w = m->final_conv;
+      const size_t lds = (size_t)w.K * w.Cin * 4;
+      dim3 grid(kk_cdiv(y.rows, 256), B);
+      if (y.dtype == KK_BF16 && w.Cin % 8 == 0 && w.Cin <= 64 && y.ld % 8 == 0 && w.K <= 16) {
+        const size_t l2 = (size_t)(256 + w.K - 1) * C1_LD * 2 + (size_t)w.K * w.Cin * 4;
+        hipLaunchKernelGGL(conv_cout1_bf16_kernel, grid, dim3(256), l2, r.st, (const bf16_t*)y.p, y.ld, y.rows, w.Cin, w.K, c.last_ksize - 1, w.w, w.ldw, w.b, 1, pcm);
+      } else if (y.dtype == KK_BF16)
+        hipLaunchKernelGGL(conv_cout1_kernel<bf16_t>, grid, dim3(256), lds, r.st, (const bf16_t*)y.p, y.ld, y.rows, w.Cin, w.K, c.last_ksize - 1, w.w, w.ldw, w.b, 1, pcm);
+      else
+        hipLaunchKernelGGL(conv_cout1_kernel<float>, grid, dim3(256), lds, r.st, (const float*)y.p, y.ld, y.rows, w.Cin, w.K, c.last_ksize - 1, w.w, w.ldw, w.b, 1, pcm);
+      KK_CHECK_LAUNCH();
+    }
+    return 0;
+  }
   MM_TRY(r.conv(m->final_conv, y, out, (c.last_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
   return 0;
 }
