@@ -201,7 +201,13 @@ size_t kk_mimi_workspace_bytes(kk_mimi* m, int B, int Nf);
 /* codes [B][nq][Nf] int32 (device) -> pcm [B][samples_per_frame * Nf] float32 (device).  Like the reference's non-streaming
  * decode the transformer attends over the WHOLE sequence (no mask reaches the attention call, transformer.py:171). */
 int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);
-/* intermediates of the last decode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3"; [B][rows][channels] fp32 */
+/* Mimi.encode (mimi.py:138-145): pcm [B][N] float32 -> codes [B][nq][kk_mimi_encode_frames(N)] int32.  Needs the
+ * encoder.*, encoder_transformer.*, downsample.*, quantizer.*.input_proj parameters; always runs on the fp32 kernels (the
+ * code-book search is an argmin). */
+int kk_mimi_encode_frames(const kk_mimi* m, int N); /* ceil chain over the ratios and the resampler: 120000 -> 63 */
+size_t kk_mimi_encode_workspace_bytes(kk_mimi* m, int B, int N);
+int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out);
+/* intermediates of the last decode / encode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3" (decode), "seanet", "transformer", "downsampled" (encode); [B][rows][channels] fp32 */
 int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels);
 int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);
 

@@ -74,6 +74,9 @@ SIGNATURES = {
     "kk_mimi_samples_per_frame": (C.c_int64, [_vp]),
     "kk_mimi_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_mimi_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "kk_mimi_encode_frames": (_i, [_vp, _i]),
+    "kk_mimi_encode_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "kk_mimi_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_debug_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kk_mimi_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_set_op_wfrag": (None, [_vp]),

@@ -69,6 +69,13 @@ struct kk_mimi {
   PackedConv proj_first, proj_rest, init_conv, final_conv;
   std::vector<MimiLayer> layers;
   std::vector<SeaLayer> sea;
+  // encode side (present when the checkpoint holds "encoder.*"): SEANet encoder, encoder transformer, resampler, RVQ search
+  bool has_encoder = false;
+  PackedConv enc_init, enc_final, enc_down, inproj_first, inproj_rest;
+  std::vector<SeaLayer> enc_sea;  // up = the strided down-sampling conv here
+  std::vector<MimiLayer> enc_layers;
+  std::vector<PackedConv> cb_dot;  // per code book: E^T as a 1x1 conv qdim -> bins (the x.e term of the distance)
+  PackedVec c2;                    // [nq][bins] |e|^2 / 2
   std::map<std::string, DebugBuf> dbg;
 };
 
@@ -229,6 +236,44 @@ __global__ __launch_bounds__(256) void conv_cout1_bf16_kernel(const bf16_t* x, i
   out[(long long)b * L + t] = acc;
 }
 
+// 'edge' padding of the resampler (conv.py:350-367, mx.pad mode="edge"): out row p = x[clamp(p - left, 0, L-1)]
+__global__ __launch_bounds__(256) void edge_pad_kernel(const float* x, int L, int C, int left, int Lp, float* out) {
+  const int p = blockIdx.x, b = blockIdx.y;
+  int r = p - left;
+  r = r < 0 ? 0 : (r >= L ? L - 1 : r);
+  for (int c = threadIdx.x; c < C; c += 256) out[((long long)b * Lp + p) * C + c] = x[((long long)b * L + r) * C + c];
+}
+
+// EuclideanCodebook.encode (quantization.py:35-39): idx = argmin_j (c2[j] - x.e_j), first index on ties; then the residual loses
+// the chosen row (quantization.py:84-92).  dots [B][T][bins] come from the 1x1 conv with E^T.
+__global__ __launch_bounds__(256) void rvq_argmin_kernel(const float* dots, const float* c2, const float* cb, int bins, int qdim, int T, int nq,
+                                                         int cbi, float* residual, int* codes) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* d = dots + ((long long)b * T + t) * bins;
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < bins; j += 256) {
+    const float v = c2[j] - d[j];
+    if (v < best) { best = v; bi = j; }  // ascending j per thread: the first minimum wins
+  }
+  sv[tid] = best; si[tid] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float v = sv[tid + s];
+      const int i = si[tid + s];
+      if (v < sv[tid] || (v == sv[tid] && i < si[tid])) { sv[tid] = v; si[tid] = i; }
+    }
+    __syncthreads();
+  }
+  const int idx = si[0];
+  if (tid == 0) codes[((long long)b * nq + cbi) * T + t] = idx;
+  float* r = residual + ((long long)b * T + t) * qdim;
+  for (int c = tid; c < qdim; c += 256) r[c] -= cb[(long long)idx * qdim + c];
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 uint16_t f32_to_bf16_rne(float f) {
@@ -335,6 +380,7 @@ struct Run {
   size_t cap, used;
   bool dry;
   bool oom = false;
+  int adt = -1;  // activation dtype of this run (-1: the model's)
   void* raw(size_t bytes) {
     const size_t off = (used + 255) & ~(size_t)255;
     used = off + bytes;
@@ -346,7 +392,7 @@ struct Run {
   // data: the kernel masks channels >= Cin)
   Act act(int rows, int C, int dtype = -1) {
     Act t;
-    t.dtype = dtype < 0 ? m->adt : dtype;
+    t.dtype = dtype < 0 ? (adt < 0 ? m->adt : adt) : dtype;
     t.rows = rows; t.C = C;
     t.ld = t.dtype == KK_BF16 ? rup(C, 64) : C;
     t.p = raw((size_t)B * rows * t.ld * (t.dtype == KK_BF16 ? 2 : 4));
@@ -401,6 +447,36 @@ struct Run {
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// x [B][T][D] updated in place by the layers (transformer.py:137-177); n, qkv, att, hbuf are scratch of the same row count
+int run_transformer(Run& r, const std::vector<MimiLayer>& layers, Act& x, Act& n, Act& qkv, Act& att, Act& hbuf) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, T = x.rows;
+  const bool bf = x.dtype == KK_BF16;
+  for (size_t l = 0; l < layers.size(); ++l) {
+    const MimiLayer& L = layers[l];
+    MM_TRY(r.layernorm(x, n, L.n1w.p, L.n1b.p));
+    MM_TRY(r.conv(L.in_proj, n, qkv, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    if (!r.dry) {
+      if (bf)
+        hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (bf16_t*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
+      else
+        hipLaunchKernelGGL(rope_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (float*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
+      KK_CHECK_LAUNCH();
+      KKAttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.qkv = qkv.p; a.bs = qkv.bs(); a.ld = qkv.ld; a.out = att.p; a.obs = att.bs(); a.ldo = att.ld;
+      a.heads = c.num_heads; a.hs = D; a.Tmax = T; a.len = KKLen{nullptr, 0, T}; a.scale = 1.0f / sqrtf((float)(D / c.num_heads));
+      MM_TRY(kk_launch_attention(a, B, qkv.dtype, r.st));
+    }
+    MM_TRY(r.conv(L.out_proj, att, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));  // x += ls1 * (W att)
+    MM_TRY(r.layernorm(x, n, L.n2w.p, L.n2b.p));
+    MM_TRY(r.conv(L.lin1, n, hbuf, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
+    MM_TRY(r.conv(L.lin2, hbuf, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));     // x += ls2 * (W2 gelu(W1 n))
+  }
+  return 0;
+}
+
 int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
   kk_mimi* m = r.m;
   const kk_mimi_config& c = m->cfg;
@@ -432,27 +508,7 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
   }
   r.note("upsampled", xu);
   // ---- transformer
-  for (int l = 0; l < c.num_layers; ++l) {
-    const MimiLayer& L = m->layers[l];
-    MM_TRY(r.layernorm(x, n, L.n1w.p, L.n1b.p));
-    MM_TRY(r.conv(L.in_proj, n, qkv, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
-    if (!r.dry) {
-      if (bf)
-        hipLaunchKernelGGL(rope_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (bf16_t*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
-      else
-        hipLaunchKernelGGL(rope_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (float*)qkv.p, m->inv_freq.p, T, D, qkv.ld, D / c.num_heads);
-      KK_CHECK_LAUNCH();
-      KKAttnArgs a;
-      memset(&a, 0, sizeof a);
-      a.qkv = qkv.p; a.bs = qkv.bs(); a.ld = qkv.ld; a.out = att.p; a.obs = att.bs(); a.ldo = att.ld;
-      a.heads = c.num_heads; a.hs = D; a.Tmax = T; a.len = KKLen{nullptr, 0, T}; a.scale = 1.0f / sqrtf((float)(D / c.num_heads));
-      MM_TRY(kk_launch_attention(a, B, qkv.dtype, r.st));
-    }
-    MM_TRY(r.conv(L.out_proj, att, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));  // x += ls1 * (W att)
-    MM_TRY(r.layernorm(x, n, L.n2w.p, L.n2b.p));
-    MM_TRY(r.conv(L.lin1, n, hbuf, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
-    MM_TRY(r.conv(L.lin2, hbuf, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));     // x += ls2 * (W2 gelu(W1 n))
-  }
+  MM_TRY(run_transformer(r, m->layers, x, n, qkv, att, hbuf));
   r.note("transformer", x);
   // ---- SEANet decoder
   Act y = r.act(T, m->init_conv.Cout);
@@ -489,6 +545,70 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
     return 0;
   }
   MM_TRY(r.conv(m->final_conv, y, out, (c.last_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  return 0;
+}
+
+int mimi_encode_frames(const kk_mimi_config& c, int N) {
+  long long L = N;
+  for (int i = c.n_ratios - 1; i >= 0; --i) L = (L + c.ratios[i] - 1) / c.ratios[i];
+  return (int)((L + c.upsample_stride - 1) / c.upsample_stride);
+}
+
+// Mimi.encode (mimi.py:138-145), always fp32: the code-book search is an argmin, so the arithmetic stays on the parity path
+int run_encode(Run& r, int N, const float* pcm, int* codes) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, Q = c.qdim;
+  r.adt = KK_F32;
+  Act x;
+  x.p = const_cast<float*>(pcm); x.rows = N; x.C = 1; x.ld = 1; x.dtype = KK_F32;
+  Act y = r.act(N, m->enc_init.Cout);
+  if (r.oom) return kk_fail("kk_mimi_encode: workspace too small");
+  MM_TRY(r.conv(m->enc_init, x, y, c.ksize - 1, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  for (size_t l = 0; l < m->enc_sea.size(); ++l) {
+    const SeaLayer& S = m->enc_sea[l];
+    Act hb = r.act(y.rows, S.b0.Cout), o = r.act(y.rows, y.C);
+    const int Lo = kk_cdiv(y.rows, S.ratio);
+    Act d = r.act(Lo, S.up.Cout);
+    if (r.oom) return kk_fail("kk_mimi_encode: workspace too small");
+    MM_TRY(r.conv(S.b0, y, hb, c.residual_ksize - 1, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.conv(S.b1, hb, o, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, &y, 0));
+    // causal strided conv: left pad k - stride, the right "extra padding" (conv.py:200-209) is the kernel's implicit zero rows
+    MM_TRY(r.conv(S.up, o, d, S.up.K - S.ratio, 1, false, S.ratio, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    y = d;
+  }
+  const int T = y.rows;
+  Act xe = r.act(T, D), n = r.act(T, D), qkv = r.act(T, 3 * D), att = r.act(T, D), hbuf = r.act(T, c.dim_feedforward);
+  if (r.oom) return kk_fail("kk_mimi_encode: workspace too small");
+  MM_TRY(r.conv(m->enc_final, y, xe, c.last_ksize - 1, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  r.note("seanet", xe);
+  Act xt = r.act(T, D);
+  if (r.oom) return kk_fail("kk_mimi_encode: workspace too small");
+  if (!r.dry && hipMemcpyAsync(xt.p, xe.p, (size_t)B * T * D * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_encode: copy failed");
+  MM_TRY(run_transformer(r, m->enc_layers, xt, n, qkv, att, hbuf));
+  r.note("transformer", xt);
+  // resampler: conv k = 2 s, stride s, 'edge' padding on both sides (ConvDownsample1d, conv.py:350-367)
+  const int s = c.upsample_stride, k = 2 * s, Nf = kk_cdiv(T, s);
+  const int left = k - s, Lp = (Nf - 1) * s + k;  // = left + T + extra
+  Act xp = r.act(Lp, D), xd = r.act(Nf, D), res = r.act(Nf, Q), dots = r.act(Nf, c.bins);
+  if (r.oom) return kk_fail("kk_mimi_encode: workspace too small");
+  if (!r.dry) {
+    hipLaunchKernelGGL(edge_pad_kernel, dim3(Lp, B), dim3(256), 0, r.st, (const float*)xt.p, T, D, left, Lp, (float*)xp.p);
+    KK_CHECK_LAUNCH();
+  }
+  MM_TRY(r.conv(m->enc_down, xp, xd, 0, 1, false, s, 0, KK_ACT_NONE, nullptr, 0));
+  r.note("downsampled", xd);
+  // split RVQ search (quantization.py:128-133,170-176): first code book on its own projection, the other nq-1 on the second
+  for (int i = 0; i < c.nq; ++i) {
+    if (i == 0) MM_TRY(r.conv(m->inproj_first, xd, res, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    if (i == 1) MM_TRY(r.conv(m->inproj_rest, xd, res, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.conv(m->cb_dot[i], res, dots, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    if (!r.dry) {
+      hipLaunchKernelGGL(rvq_argmin_kernel, dim3(Nf, B), dim3(256), 0, r.st, (const float*)dots.p, m->c2.p + (size_t)i * c.bins,
+                         m->codebooks.p + (size_t)i * c.bins * Q, c.bins, Q, Nf, c.nq, i, (float*)res.p, codes);
+      KK_CHECK_LAUNCH();
+    }
+  }
   return 0;
 }
 
@@ -561,18 +681,67 @@ extern "C" int kk_mimi_finalize(kk_mimi* m, void* stream) {
     m->inv_freq.off = P.alloc(half);
     memcpy(&m->pack[m->inv_freq.off], f.data(), half * 4);
   }
-  m->layers.resize(c.num_layers);
-  for (int l = 0; l < c.num_layers; ++l) {
-    const std::string p = "decoder_transformer.transformer.layers." + std::to_string(l);
-    MimiLayer& L = m->layers[l];
-    L.n1w = P.vec(p + ".norm1.weight", D); L.n1b = P.vec(p + ".norm1.bias", D);
-    L.n2w = P.vec(p + ".norm2.weight", D); L.n2b = P.vec(p + ".norm2.bias", D);
-    L.in_proj = P.conv(p + ".self_attn.in_proj.weight", "", 3 * D, 1, D);
-    const std::vector<float>* s1 = P.get(p + ".layer_scale_1.scale", D);
-    const std::vector<float>* s2 = P.get(p + ".layer_scale_2.scale", D);
-    L.out_proj = P.conv(p + ".self_attn.out_proj.weight", "", D, 1, D, s1);
-    L.lin1 = P.conv(p + ".gating.linear1.weight", "", c.dim_feedforward, 1, D);
-    L.lin2 = P.conv(p + ".gating.linear2.weight", "", D, 1, c.dim_feedforward, s2);
+  auto pack_transformer = [&](const std::string& stack, std::vector<MimiLayer>& layers) {
+    layers.resize(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+      const std::string p = stack + ".transformer.layers." + std::to_string(l);
+      MimiLayer& L = layers[l];
+      L.n1w = P.vec(p + ".norm1.weight", D); L.n1b = P.vec(p + ".norm1.bias", D);
+      L.n2w = P.vec(p + ".norm2.weight", D); L.n2b = P.vec(p + ".norm2.bias", D);
+      L.in_proj = P.conv(p + ".self_attn.in_proj.weight", "", 3 * D, 1, D);
+      const std::vector<float>* s1 = P.get(p + ".layer_scale_1.scale", D);
+      const std::vector<float>* s2 = P.get(p + ".layer_scale_2.scale", D);
+      L.out_proj = P.conv(p + ".self_attn.out_proj.weight", "", D, 1, D, s1);
+      L.lin1 = P.conv(p + ".gating.linear1.weight", "", c.dim_feedforward, 1, D);
+      L.lin2 = P.conv(p + ".gating.linear2.weight", "", D, 1, c.dim_feedforward, s2);
+    }
+  };
+  pack_transformer("decoder_transformer", m->layers);
+  // ---- encode side, when the checkpoint has it
+  m->has_encoder = m->host.count("encoder.init_conv1d.conv.conv.weight") != 0;
+  if (m->has_encoder) {
+    const int saved = m->adt;
+    m->adt = KK_F32;  // the encoder runs on the fp32 kernels only: no fragment packs
+    int em = 1;
+    m->enc_init = P.conv("encoder.init_conv1d.conv.conv.weight", "encoder.init_conv1d.conv.conv.bias", c.nfilters, c.ksize, 1);
+    m->enc_sea.resize(c.n_ratios);
+    for (int l = 0; l < c.n_ratios; ++l) {
+      const std::string p = "encoder.layers." + std::to_string(l);
+      const int dim = em * c.nfilters, hid = dim / c.compress;
+      SeaLayer& S = m->enc_sea[l];
+      S.ratio = c.ratios[c.n_ratios - 1 - l];  // reversed(cfg.ratios), seanet.py:187
+      S.b0 = P.conv(p + ".residuals.0.block.0.conv.conv.weight", p + ".residuals.0.block.0.conv.conv.bias", hid, c.residual_ksize, dim);
+      S.b1 = P.conv(p + ".residuals.0.block.1.conv.conv.weight", p + ".residuals.0.block.1.conv.conv.bias", dim, 1, hid);
+      S.up = P.conv(p + ".downsample.conv.conv.weight", p + ".downsample.conv.conv.bias", 2 * dim, 2 * S.ratio, dim);
+      em *= 2;
+    }
+    m->enc_final = P.conv("encoder.final_conv1d.conv.conv.weight", "encoder.final_conv1d.conv.conv.bias", D, c.last_ksize, em * c.nfilters);
+    m->enc_down = P.conv("downsample.conv.conv.conv.weight", "", D, 2 * c.upsample_stride, D);
+    m->inproj_first = P.conv("quantizer.rvq_first.input_proj.weight", "", Q, 1, D);
+    if (c.nq > 1) m->inproj_rest = P.conv("quantizer.rvq_rest.input_proj.weight", "", Q, 1, D);
+    pack_transformer("encoder_transformer", m->enc_layers);
+    // distance tables: c2 = |e|^2 / 2 and E^T as a 1x1 conv (quantization.py:27-28,35-39)
+    m->c2.n = c.nq * c.bins;
+    m->c2.off = P.alloc((size_t)m->c2.n);
+    m->cb_dot.resize(c.nq);
+    for (int i = 0; i < c.nq; ++i) {
+      PackedConv& cd = m->cb_dot[i];
+      cd.Cin = Q; cd.Cout = c.bins; cd.K = 1; cd.ldw = rup(c.bins, 64);
+      cd.w_off = P.alloc((size_t)Q * cd.ldw);
+      const float* E = &m->pack[m->codebooks.off + (size_t)i * c.bins * Q];
+      float* dst = &m->pack[cd.w_off];
+      float* c2 = &m->pack[m->c2.off + (size_t)i * c.bins];
+      for (int r = 0; r < c.bins; ++r) {
+        float ss = 0.f;
+        for (int q = 0; q < Q; ++q) {
+          const float e = E[(size_t)r * Q + q];
+          dst[(size_t)q * cd.ldw + r] = e;
+          ss += e * e;
+        }
+        c2[r] = ss / 2.0f;
+      }
+    }
+    m->adt = saved;
   }
   int mult = 1 << c.n_ratios;
   m->init_conv = P.conv("decoder.init_conv1d.conv.conv.weight", "decoder.init_conv1d.conv.conv.bias", mult * c.nfilters, c.ksize, D);
@@ -600,6 +769,16 @@ extern "C" int kk_mimi_finalize(kk_mimi* m, void* stream) {
     resolve(m, L.in_proj); resolve(m, L.out_proj); resolve(m, L.lin1); resolve(m, L.lin2);
   }
   for (auto& S : m->sea) { resolve(m, S.up); resolve(m, S.b0); resolve(m, S.b1); }
+  if (m->has_encoder) {
+    resolve(m, m->enc_init); resolve(m, m->enc_final); resolve(m, m->enc_down); resolve(m, m->inproj_first); resolve(m, m->inproj_rest);
+    resolve(m, m->c2);
+    for (auto& S : m->enc_sea) { resolve(m, S.up); resolve(m, S.b0); resolve(m, S.b1); }
+    for (auto& L : m->enc_layers) {
+      resolve(m, L.n1w); resolve(m, L.n1b); resolve(m, L.n2w); resolve(m, L.n2b);
+      resolve(m, L.in_proj); resolve(m, L.out_proj); resolve(m, L.lin1); resolve(m, L.lin2);
+    }
+    for (auto& cd : m->cb_dot) resolve(m, cd);
+  }
   m->host.clear();
   std::vector<float>().swap(m->pack);
   m->finalized = true;
@@ -628,6 +807,26 @@ extern "C" int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int
   m->dbg.clear();
   Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   return run_decode(r, Nf, codes, pcm_out);
+}
+
+extern "C" int kk_mimi_encode_frames(const kk_mimi* m, int N) { return (m && N > 0) ? mimi_encode_frames(m->cfg, N) : 0; }
+
+extern "C" size_t kk_mimi_encode_workspace_bytes(kk_mimi* m, int B, int N) {
+  if (!m || !m->finalized || !m->has_encoder || B <= 0 || N <= 0) return 0;
+  Run r{m, nullptr, B, nullptr, 0, 0, true, false};
+  if (run_encode(r, N, nullptr, nullptr) != 0) return 0;
+  return r.used + 256;
+}
+
+extern "C" int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const float* pcm, void* workspace, size_t workspace_bytes,
+                              int32_t* codes_out) {
+  if (!m || !m->finalized) return kk_fail("kk_mimi_encode: model not finalized");
+  if (!m->has_encoder) return kk_fail("kk_mimi_encode: the checkpoint held no encoder.* parameters");
+  if (B <= 0 || N <= 0 || !pcm || !workspace || !codes_out) return kk_fail("kk_mimi_encode: bad argument");
+  if (workspace_bytes < kk_mimi_encode_workspace_bytes(m, B, N)) return kk_fail("kk_mimi_encode: workspace too small");
+  m->dbg.clear();
+  Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
+  return run_encode(r, N, pcm, codes_out);
 }
 
 // named intermediates of the LAST decode call (tests): "quantized", "upsampled", "transformer", "layer0".."layer3"

@@ -1,6 +1,7 @@
 """Host mirror of the reference's Mimi codec surface for the DECODE path (mlx_audio/codec/models/mimi/mimi.py): `mimi_202407`,
 `Mimi(cfg)`, `Mimi.decode(codes)`, `.sample_rate`, `.frame_rate`.  The arithmetic runs in libkokoro_hip.so (kk_mimi_*, csrc/kk_mimi.hip);
-PyTorch allocates device memory and provides the stream.  Encoding (Mimi.encode, mimi.py:138-145) is not built."""
+PyTorch allocates device memory and provides the stream.  `Mimi.encode` (mimi.py:138-145) runs on the fp32 kernels; the streaming
+`*_step` entry points are not built."""
 from __future__ import annotations
 
 import ctypes as C
@@ -122,6 +123,27 @@ class Mimi:
             check(self.lib.kk_mimi_decode(self._h, self._stream(), B, Nf, C.c_void_p(codes.data_ptr()), C.c_void_p(self._ws.data_ptr()), need,
                                           C.c_void_p(pcm.data_ptr())), "kk_mimi_decode")
         return pcm
+
+    def encode(self, xs) -> torch.Tensor:
+        """pcm [B, 1, N] float -> codes [B, nq, ceil-chain(N)] int32 on the device (mimi.py:138-145)."""
+        if not self._final:
+            raise KokoroHipError("Mimi.encode: load_weights first")
+        xs = torch.as_tensor(xs).to(device=self.device, dtype=torch.float32).contiguous()
+        if xs.ndim != 3 or xs.shape[1] != 1:
+            raise ValueError(f"pcm must be [B, 1, N], got {tuple(xs.shape)}")
+        B, _, N = xs.shape
+        self._last_B = B
+        with torch.cuda.device(self.device):
+            need = int(self.lib.kk_mimi_encode_workspace_bytes(self._h, B, N))
+            if need == 0:
+                raise KokoroHipError("kk_mimi_encode_workspace_bytes failed (no encoder parameters loaded?)")
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            nf = int(self.lib.kk_mimi_encode_frames(self._h, N))
+            codes = torch.empty((B, self.cfg.nq, nf), dtype=torch.int32, device=self.device)
+            check(self.lib.kk_mimi_encode(self._h, self._stream(), B, N, C.c_void_p(xs.data_ptr()), C.c_void_p(self._ws.data_ptr()), need,
+                                          C.c_void_p(codes.data_ptr())), "kk_mimi_encode")
+        return codes
 
     def debug_fetch(self, name: str) -> torch.Tensor:
         rows, ch = C.c_int64(0), C.c_int64(0)

@@ -331,10 +331,44 @@ def mimi_tiny_config() -> dict:
                 sample_rate=24000, frame_rate=12.5)
 
 
-def mimi_param_inventory(cfg: dict) -> dict:
-    """MLX-side names and shapes of everything Mimi.decode reads (after load_pytorch_weights' remap, mimi.py:184-249)."""
+def mimi_param_inventory(cfg: dict, encode: bool = False) -> dict:
+    """MLX-side names and shapes of everything Mimi.decode (and, with encode=True, Mimi.encode) reads (after load_pytorch_weights'
+    remap, mimi.py:184-249)."""
     D, Q = cfg["dim"], cfg["qdim"]
     inv = {}
+    if encode:
+        nf = cfg["nfilters"]
+        inv["encoder.init_conv1d.conv.conv.weight"] = (nf, cfg["ksize"], 1)
+        inv["encoder.init_conv1d.conv.conv.bias"] = (nf,)
+        mult = 1
+        for l, r in enumerate(reversed(cfg["ratios"])):
+            dim = mult * nf
+            hid = dim // cfg["compress"]
+            p = f"encoder.layers.{l}"
+            inv[f"{p}.residuals.0.block.0.conv.conv.weight"] = (hid, cfg["residual_ksize"], dim)
+            inv[f"{p}.residuals.0.block.0.conv.conv.bias"] = (hid,)
+            inv[f"{p}.residuals.0.block.1.conv.conv.weight"] = (dim, 1, hid)
+            inv[f"{p}.residuals.0.block.1.conv.conv.bias"] = (dim,)
+            inv[f"{p}.downsample.conv.conv.weight"] = (2 * dim, 2 * r, dim)
+            inv[f"{p}.downsample.conv.conv.bias"] = (2 * dim,)
+            mult *= 2
+        inv["encoder.final_conv1d.conv.conv.weight"] = (D, cfg["last_ksize"], mult * nf)
+        inv["encoder.final_conv1d.conv.conv.bias"] = (D,)
+        inv["downsample.conv.conv.conv.weight"] = (D, 2 * cfg["upsample_stride"], D)
+        for which in ("rvq_first", "rvq_rest"):
+            if which == "rvq_first" or cfg["nq"] > 1:
+                inv[f"quantizer.{which}.input_proj.weight"] = (Q, 1, D)
+        for i in range(cfg["num_layers"]):
+            p = f"encoder_transformer.transformer.layers.{i}"
+            for nm in ("norm1", "norm2"):
+                inv[f"{p}.{nm}.weight"] = (D,)
+                inv[f"{p}.{nm}.bias"] = (D,)
+            inv[f"{p}.self_attn.in_proj.weight"] = (3 * D, D)
+            inv[f"{p}.self_attn.out_proj.weight"] = (D, D)
+            inv[f"{p}.layer_scale_1.scale"] = (D,)
+            inv[f"{p}.layer_scale_2.scale"] = (D,)
+            inv[f"{p}.gating.linear1.weight"] = (cfg["dim_feedforward"], D)
+            inv[f"{p}.gating.linear2.weight"] = (D, cfg["dim_feedforward"])
     for which, n in (("rvq_first", 1), ("rvq_rest", cfg["nq"] - 1)):
         for i in range(n):
             inv[f"quantizer.{which}.vq.layers.{i}.codebook.embedding_sum"] = (cfg["bins"], Q)
@@ -373,11 +407,15 @@ def mimi_param_inventory(cfg: dict) -> dict:
     return inv
 
 
-def mimi_synth_checkpoint(cfg: dict, seed: int = 0) -> dict:
-    """Seeded random-init decode-side checkpoint (fan-in scaled so activations stay O(1); no real weights exist offline)."""
+def mimi_synth_checkpoint(cfg: dict, seed: int = 0, encode: bool = False) -> dict:
+    """Seeded random-init checkpoint (fan-in scaled so activations stay O(1); no real weights exist offline).  The decode-side
+    tensors do not depend on `encode` (they are drawn first)."""
     rng = np.random.default_rng(seed)
     w = {}
-    for name, shape in mimi_param_inventory(cfg).items():
+    inv = mimi_param_inventory(cfg)
+    if encode:
+        inv.update({k: v for k, v in mimi_param_inventory(cfg, encode=True).items() if k not in inv})
+    for name, shape in inv.items():
         if name.endswith("embedding_sum"):
             w[name] = (0.25 * rng.standard_normal(shape)).astype(np.float32)
         elif name.endswith("cluster_usage"):

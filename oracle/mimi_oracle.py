@@ -98,7 +98,7 @@ class MimiOracle:
         out[..., 1::2] = x0 * s + x1 * c
         return out
 
-    def transformer(self, x: torch.Tensor) -> torch.Tensor:
+    def transformer(self, x: torch.Tensor, prefix: str = "decoder_transformer") -> torch.Tensor:
         """ProjectedTransformer with conv_layout (:213-247): [B,C,T] -> [B,T,C] -> layers -> back."""
         cfg = self.cfg
         H = cfg["num_heads"]
@@ -106,7 +106,7 @@ class MimiOracle:
         Bn, T, C = x.shape
         hd = C // H
         for i in range(cfg["num_layers"]):
-            p = f"decoder_transformer.transformer.layers.{i}"
+            p = f"{prefix}.transformer.layers.{i}"
             n1 = F.layer_norm(x, (C,), t(self.w[p + ".norm1.weight"]), t(self.w[p + ".norm1.bias"]), 1e-5)
             qkv = (n1 @ t(self.w[p + ".self_attn.in_proj.weight"]).T).reshape(Bn, T, 3, H, hd)
             q, k, v = [qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3)]
@@ -133,6 +133,62 @@ class MimiOracle:
             if inter is not None:
                 inter[f"layer{l}"] = x.numpy()
         return self.causal_conv(F.elu(x), "decoder.final_conv1d")
+
+    # ---- encode side: seanet.py:120-212 (encoder), conv.py:232-263,350-367 (strided causal conv, 'edge' resampler),
+    #      quantization.py:35-39,62-66,84-92,128-133,170-176 (argmin of c2 - x.e, residual loop), mimi.py:138-145
+    def strided_causal_conv(self, x: torch.Tensor, prefix: str, stride: int, pad_mode: str = "constant") -> torch.Tensor:
+        w = t(self.w[prefix + ".conv.conv.weight"])
+        b = t(self.w[prefix + ".conv.conv.bias"]) if prefix + ".conv.conv.bias" in self.w else None
+        k = w.shape[1]
+        padding_total = k - stride
+        L = x.shape[-1]
+        nframes = max(L + padding_total - k, 0) / stride + 1.0  # get_extra_padding_for_conv1d (conv.py:200-209)
+        ideal = (int(math.ceil(nframes)) - 1) * stride + k - padding_total
+        extra = max(0, ideal - L)
+        x = F.pad(x, (padding_total, extra), mode="replicate" if pad_mode == "edge" else "constant")
+        return F.conv1d(x, w.permute(0, 2, 1), b, stride=stride)
+
+    def seanet_encoder(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.causal_conv(x, "encoder.init_conv1d")
+        for l, r in enumerate(reversed(self.cfg["ratios"])):
+            p = f"encoder.layers.{l}"
+            res = x
+            y = self.causal_conv(F.elu(x), p + ".residuals.0.block.0", 1)
+            y = self.causal_conv(F.elu(y), p + ".residuals.0.block.1", 1)
+            x = y + res
+            x = self.strided_causal_conv(F.elu(x), p + ".downsample", r)
+        return self.causal_conv(F.elu(x), "encoder.final_conv1d")
+
+    def rvq_encode(self, which: str, x: torch.Tensor, n: int, trace: list | None = None) -> np.ndarray:
+        """x [B, dim, T] -> codes [B, n, T].  Distances c2 - x.e with c2 = |e|^2 / 2 (quantization.py:27-28,35-39)."""
+        w = t(self.w[f"quantizer.{which}.input_proj.weight"]).permute(0, 2, 1)
+        residual = F.conv1d(x, w).transpose(1, 2)  # [B, T, qdim]
+        codes = []
+        for i in range(n):
+            E = self.codebook(f"quantizer.{which}.vq.layers.{i}.codebook")
+            c2 = (E * E).sum(-1) / 2
+            dist = c2[None, None, :] - residual @ E.T
+            idx = dist.argmin(-1)
+            if trace is not None:
+                trace.append((which, i, dist.numpy().copy(), idx.numpy().copy()))
+            residual = residual - E[idx]
+            codes.append(idx.numpy())
+        return np.stack(codes, axis=1)
+
+    def encode(self, pcm: np.ndarray, trace: list | None = None, return_inter: bool = False):
+        """Mimi.encode (mimi.py:138-145): pcm [B, 1, N] -> codes [B, nq, ceil(N / 1920)]."""
+        with torch.no_grad():
+            inter = {}
+            x = self.seanet_encoder(t(pcm))
+            inter["seanet"] = x.numpy()
+            x = self.transformer(x, prefix="encoder_transformer")
+            inter["transformer"] = x.numpy()
+            x = self.strided_causal_conv(x, "downsample.conv", self.cfg["upsample_stride"], pad_mode="edge")
+            inter["downsampled"] = x.numpy()
+            codes = self.rvq_encode("rvq_first", x, 1, trace)
+            if self.cfg["nq"] > 1:
+                codes = np.concatenate([codes, self.rvq_encode("rvq_rest", x, self.cfg["nq"] - 1, trace)], axis=1)
+        return (codes, inter) if return_inter else codes
 
     # ---- mimi.py:147-154 -------------------------------------------------------------------------------------------
     def decode(self, codes: np.ndarray, return_inter: bool = False):

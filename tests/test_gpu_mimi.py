@@ -104,3 +104,46 @@ def test_mimi_reference_shape_known_answer_on_gpu():
     assert model.sample_rate == 24000 and model.frame_rate == 12.5
     with pytest.raises(ValueError):
         model.decode(torch.zeros((1, 31, 5), dtype=torch.int64))
+
+
+@pytest.mark.parametrize("which", ["tiny", "202407"])
+def test_mimi_encode_matches_oracle(which):
+    """Mimi.encode (row C5): the continuous stages within 2e-4; the codes equal to the oracle's, except where the two best
+    code-book entries are a genuine near-tie at the FIRST differing code book of a frame (distance gap < 1e-4 of the spread) --
+    after such a flip the residual differs and the later code books of that frame are not comparable."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+
+    cfg = P.mimi_tiny_config() if which == "tiny" else P.mimi_config(32)
+    w = P.mimi_synth_checkpoint(cfg, 6, encode=True)
+    rng = np.random.default_rng(66)
+    B, N = (3, 1920 * 6 + 777) if which == "tiny" else (2, 1920 * 8 + 100)
+    pcm = (0.3 * rng.standard_normal((B, 1, N))).astype(np.float32)
+    trace = []
+    ref, inter = M.MimiOracle(w, cfg).encode(pcm, trace=trace, return_inter=True)
+    model = Mimi(MimiConfig.from_dict(cfg), w)
+    codes = model.encode(torch.tensor(pcm))
+    torch.cuda.synchronize()
+    got = codes.cpu().numpy()
+    assert got.shape == ref.shape
+    for name in ("seanet", "transformer", "downsampled"):
+        g = model.debug_fetch(name).cpu().numpy()
+        e = err_stats(g, np.transpose(inter[name], (0, 2, 1)))
+        report(f"mimi_encode/{which}/{name}", **e)
+        assert e["rel_max"] < 2e-4, (name, e)
+    nq, Nf = ref.shape[1], ref.shape[2]
+    frames_equal = 0
+    for b in range(B):
+        for t in range(Nf):
+            diff = np.nonzero(got[b, :, t] != ref[b, :, t])[0]
+            if diff.size == 0:
+                frames_equal += 1
+                continue
+            i = int(diff[0])  # first differing code book: same residual on both sides up to round-off
+            dist = trace[i][2][b, t]
+            gap = abs(float(dist[got[b, i, t]]) - float(dist[ref[b, i, t]]))
+            assert gap < 1e-4 * float(dist.max() - dist.min()), (b, t, i, gap)
+    report(f"mimi_encode/{which}/frames_with_identical_codes", value=frames_equal, total=B * Nf, max_abs=0.0, ref_max=1.0, rel_max=0.0, rms_rel=0.0)
+    assert frames_equal >= 0.9 * B * Nf
+    # decode(encode(x)) has the length of whole frames
+    out = model.decode(codes)
+    assert tuple(out.shape) == (B, 1, 1920 * Nf)

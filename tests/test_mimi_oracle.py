@@ -43,3 +43,30 @@ def test_decode_is_batch_independent_and_not_causal_in_the_transformer():
     # never-used code-book entries (cluster_usage = 0) decode through the 1e-5 floor (quantization.py:25-28)
     c3 = np.zeros_like(codes)
     assert np.isfinite(orc.decode(c3)).all()
+
+
+def test_reference_encode_shape_known_answer_and_round_trip_lengths():
+    """test_mimi.py: audio [1, 1, 120000] encodes to codes [1, 32, 63]; decoding them gives [1, 1, 120960]."""
+    cfg = P.mimi_config(32)
+    w = P.mimi_synth_checkpoint(cfg, 0, encode=True)
+    orc = M.MimiOracle(w, cfg)
+    codes = orc.encode(np.zeros((1, 1, 120_000), np.float32))
+    assert codes.shape == (1, 32, 63) and codes.min() >= 0 and codes.max() < 2048
+    assert orc.decode(codes).shape == (1, 1, 120_960)
+
+
+def test_encode_finds_the_nearest_code_and_is_causal_before_the_transformer():
+    cfg = P.mimi_tiny_config()
+    w = P.mimi_synth_checkpoint(cfg, 2, encode=True)
+    orc = M.MimiOracle(w, cfg)
+    rng = np.random.default_rng(3)
+    pcm = (0.3 * rng.standard_normal((2, 1, 1920 * 4 + 333))).astype(np.float32)
+    trace = []
+    codes, inter = orc.encode(pcm, trace=trace, return_inter=True)
+    assert codes.shape == (2, cfg["nq"], 5)  # ceil chain: 8013 -> 2004 -> 401 -> 67 -> 9 -> 5
+    for which, i, dist, idx in trace:  # the chosen entry is the exact minimiser of the stated distance
+        np.testing.assert_array_equal(idx, dist.argmin(-1))
+    p2 = pcm.copy()
+    p2[..., -200:] += 0.5  # the SEANet encoder is causal: early frames do not move
+    _, i2 = orc.encode(p2, return_inter=True)
+    np.testing.assert_array_equal(inter["seanet"][..., :6], i2["seanet"][..., :6])
