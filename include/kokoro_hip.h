@@ -211,6 +211,40 @@ int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const float* pcm, voi
 int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels);
 int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);
 
+/* =====================================================================================================================
+ * CSM-1B frame generator (rows C1-C3): SesameModel.generate_frame, mlx_audio/tts/models/sesame/sesame.py:349-395, with the
+ * Llama stacks of mlx_lm (LlamaModel + the reference's Attention / Llama3ScaledRoPE, attention.py).  fp32 in round 1.
+ * ===================================================================================================================== */
+typedef struct kk_csm kk_csm;
+typedef struct kk_llama_args { /* sesame.py:225-273 */
+  int32_t num_layers, num_heads, num_kv_heads, head_dim, hidden, intermediate;
+  float rope_theta, rope_factor, rms_eps; /* 500000, 32 (llama3 scaling: low 1, high 4, old context 8192), 1e-5 */
+} kk_llama_args;
+typedef struct kk_csm_config {
+  int32_t text_vocab_size, audio_vocab_size, audio_num_codebooks, max_seq_len; /* 128256, 2051, 32, 2048 */
+  kk_llama_args backbone, decoder;                                              /* llama-1B, llama-100M */
+} kk_csm_config;
+
+int kk_csm_create(const kk_csm_config* cfg, kk_csm** out);
+void kk_csm_destroy(kk_csm* m);
+/* MLX-side names: {backbone,decoder}.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,
+ * post_attention_layernorm}.weight, {backbone,decoder}.norm.weight, text_embeddings.weight, audio_embeddings.weight,
+ * projection.weight, codebook0_head.weight, audio_head [n_cb-1][decoder_dim][audio_vocab]; host fp32 */
+int kk_csm_load_tensor(kk_csm* m, const char* name, const int64_t* shape, int ndim, const float* data);
+int kk_csm_finalize(kk_csm* m, void* stream);
+int kk_csm_setup_caches(kk_csm* m, int max_batch); /* SesameModel.setup_caches (sesame.py:320-333): library-owned KV caches */
+int kk_csm_reset_caches(kk_csm* m);                /* sesame.py:338-345: positions restart at 0 */
+int kk_csm_position(const kk_csm* m);              /* tokens in the backbone cache */
+size_t kk_csm_workspace_bytes(kk_csm* m, int B, int S);
+/* One audio frame.  tokens [B][S][n_cb+1] int32 and tokens_mask (same shape, float 0/1) on the device; the S new positions continue
+ * the backbone cache (a block of S > 1 must start an empty cache, as index_causal_mask implies, sesame.py:41-48).  Sampling:
+ * temperature == 0 or uniforms == NULL -> argmax (make_sampler's rule for temp 0); otherwise inverse CDF over the top_k (<= 64)
+ * logits of softmax(logit / temperature) in descending order with the injected uniforms [B][n_cb] -- the distribution of
+ * make_sampler(temp, top_k) with a reproducible draw.  codes_out [B][n_cb] int32. */
+int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, const int32_t* tokens, const float* tokens_mask, float temperature, int top_k,
+                          const float* uniforms, void* workspace, size_t workspace_bytes, int32_t* codes_out);
+int kk_csm_debug_logits(kk_csm* m, void* stream, int B, float* dst); /* logits of the last frame, [n_cb][B][audio_vocab] */
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,16 @@ class KKMimiConfig(C.Structure):
     ]
 
 
+class KKLlamaArgs(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+                ("hidden", C.c_int32), ("intermediate", C.c_int32), ("rope_theta", C.c_float), ("rope_factor", C.c_float), ("rms_eps", C.c_float)]
+
+
+class KKCsmConfig(C.Structure):
+    _fields_ = [("text_vocab_size", C.c_int32), ("audio_vocab_size", C.c_int32), ("audio_num_codebooks", C.c_int32), ("max_seq_len", C.c_int32),
+                ("backbone", KKLlamaArgs), ("decoder", KKLlamaArgs)]
+
+
 # every symbol include/kokoro_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
@@ -67,6 +77,16 @@ SIGNATURES = {
     "kk_debug_clear": (None, [_vp]),
     "kk_debug_force_generic": (None, [_vp, _i]),
     "kk_op_pack_w_frag": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "kk_csm_create": (_i, [C.POINTER(KKCsmConfig), C.POINTER(_vp)]),
+    "kk_csm_destroy": (None, [_vp]),
+    "kk_csm_load_tensor": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), _i, _vp]),
+    "kk_csm_finalize": (_i, [_vp, _vp]),
+    "kk_csm_setup_caches": (_i, [_vp, _i]),
+    "kk_csm_reset_caches": (_i, [_vp]),
+    "kk_csm_position": (_i, [_vp]),
+    "kk_csm_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "kk_csm_generate_frame": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _sz, _vp]),
+    "kk_csm_debug_logits": (_i, [_vp, _vp, _i, _vp]),
     "kk_mimi_create": (_i, [C.POINTER(KKMimiConfig), C.POINTER(_vp)]),
     "kk_mimi_destroy": (None, [_vp]),
     "kk_mimi_load_tensor": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), _i, _vp]),

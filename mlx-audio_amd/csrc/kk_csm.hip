@@ -1,0 +1,629 @@
+// CSM-1B frame generator: SesameModel.generate_frame, mlx_audio/tts/models/sesame/sesame.py:349-395
+//   tokens [B][S][n_cb+1] -> masked sum of 33 embeddings -> Llama backbone (KV cache) -> codebook0 head -> sample ->
+//   31 x { projection -> Llama depth decoder (fresh cache per frame) -> audio_head[i-1] -> sample -> embed } -> codes [B][n_cb]
+// Llama layer (mlx_lm LlamaModel with the reference's Attention, sesame.py:296-299; attention.py:113-195):
+//   h += Wo . attn(rope(Wq x), rope(Wk x), Wv x), x = rms(h);   h += Wdown (silu(Wgate x) * Wup x), x = rms(h);   final rms
+//   RoPE: interleaved pairs, llama3-scaled frequencies (attention.py:33-110); GQA: query head h reads kv head h / (H / KV);
+//   mask: causal inside the new block, every cached key visible (sesame.py:37-48).
+// Round 1: fp32, the library's generic conv kernel for every linear (M = B*S rows is tiny in the decode loop), one simple attention
+// kernel for both head sizes.  The KV caches are library-owned device memory (kk_csm_setup_caches), like the module-owned caches of
+// the reference (sesame.py:320-333).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kokoro_hip.h"
+#include "kk_common.h"
+#include "kk_kernels.h"
+
+namespace {
+
+struct Lin {  // generic-kernel pack [1][Cin][ldw]
+  size_t off = 0;
+  int Cin = 0, Cout = 0, ldw = 0;
+  const float* w = nullptr;
+};
+struct Vec {
+  size_t off = 0;
+  size_t n = 0;
+  const float* p = nullptr;
+};
+struct LlamaLayer {
+  Lin qkv, o, gu, down;
+  Vec n1, n2;
+};
+struct Stack {
+  kk_llama_args a;
+  std::vector<LlamaLayer> layers;
+  Vec norm, rope;  // rope: [max_pos][hd/2][2] cos, sin
+  float* kc = nullptr;  // [layers][maxB][max_pos][KV*hd]
+  float* vc = nullptr;
+  int max_pos = 0, offset = 0;
+};
+
+}  // namespace
+
+struct kk_csm {
+  kk_csm_config cfg;
+  std::map<std::string, std::vector<float>> host;
+  std::vector<float> pack;
+  float* dev = nullptr;
+  bool finalized = false;
+  Stack bb, dec;
+  Vec text_emb, audio_emb;
+  Lin proj, c0_head;
+  std::vector<Lin> audio_head;
+  int max_batch = 0;
+  float* dbg_logits = nullptr;  // [n_cb][maxB][V] of the last frame
+};
+
+namespace {
+
+int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------------------- kernels
+// h[b][s][:] = sum_j mask[b][s][j] * emb_j(tokens[b][s][j]),  j < n_cb: audio_embeddings[token + j*V], j = n_cb: text_embeddings
+__global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const float* mask, const float* audio, const float* text, int ncb, int V,
+                                                        int D, float* h) {
+  const long long row = blockIdx.x;  // b*S + s
+  const int* tk = tokens + row * (ncb + 1);
+  const float* mk = mask + row * (ncb + 1);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j <= ncb; ++j) {
+      const float* e = j < ncb ? audio + ((long long)tk[j] + (long long)j * V) * D : text + (long long)tk[j] * D;
+      acc += e[c] * mk[j];
+    }
+    h[row * D + c] = acc;
+  }
+}
+
+// rows of audio_embeddings for code book `cb`: out[b][pos][:] = audio[(codes[b] + cb*V)][:]   (out row pitch = rows*D per item)
+__global__ __launch_bounds__(256) void embed_audio_kernel(const int* codes, int cstride, const float* audio, int cb, int V, int D, float* out, int rows,
+                                                          int pos) {
+  const int b = blockIdx.x;
+  const float* e = audio + ((long long)codes[(long long)b * cstride] + (long long)cb * V) * D;
+  for (int c = threadIdx.x; c < D; c += 256) out[((long long)b * rows + pos) * D + c] = e[c];
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, long long sbs, float* dst, long long dbs, int D) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) dst[(long long)b * dbs + c] = src[(long long)b * sbs + c];
+}
+
+// RMSNorm over the last axis, fp32: x * rsqrt(mean(x^2) + eps) * w
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const float* w, int D, float eps, float* out) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* xr = x + row * D;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) ss = __builtin_fmaf(xr[c], xr[c], ss);
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float r = 1.0f / sqrtf(tot / (float)D + eps);
+  for (int c = threadIdx.x; c < D; c += 256) out[row * D + c] = xr[c] * r * w[c];
+}
+
+// RoPE on q (in place) and k, then k / v of the new rows go into the cache at [offset + s]
+__global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int H, int KV, int hd, const float* rope, int offset, float* kc, float* vc,
+                                                          int max_pos) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int W = (H + 2 * KV) * hd, half = hd / 2;
+  float* row = qkv + ((long long)b * S + s) * W;
+  const float* cs = rope + (long long)(offset + s) * half * 2;
+  float* kdst = kc + ((long long)b * max_pos + offset + s) * KV * hd;
+  float* vdst = vc + ((long long)b * max_pos + offset + s) * KV * hd;
+  for (int e = threadIdx.x; e < (H + KV) * half; e += 256) {
+    const int hh = e / half, i = e - hh * half;
+    float* p = row + hh * hd + 2 * i;  // q heads first, k heads right behind them
+    const float c = cs[2 * i], sn = cs[2 * i + 1];
+    const float x0 = p[0], x1 = p[1];
+    const float y0 = x0 * c - x1 * sn, y1 = x1 * c + x0 * sn;
+    if (hh < H) {
+      p[0] = y0; p[1] = y1;
+    } else {
+      kdst[(hh - H) * hd + 2 * i] = y0;
+      kdst[(hh - H) * hd + 2 * i + 1] = y1;
+    }
+  }
+  const float* vsrc = row + (H + KV) * hd;
+  for (int e = threadIdx.x; e < KV * hd; e += 256) vdst[e] = vsrc[e];
+}
+
+// one workgroup per (query s, head h, item b): scores over the cached keys 0 .. offset+s, softmax, weighted sum of V
+__global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, int offset, const float* kc, const float* vc,
+                                                         int max_pos, float scale, float* out) {
+  extern __shared__ float sc[];  // [nkeys]
+  __shared__ float red[2];
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = offset + s + 1;
+  const float* q = qkv + ((long long)b * S + s) * W + h * hd;
+  const float* kb = kc + ((long long)b * max_pos) * KV * hd + kvh * hd;
+  const float* vb = vc + ((long long)b * max_pos) * KV * hd + kvh * hd;
+  float mx = -INFINITY;
+  for (int j = tid; j < nk; j += 128) {
+    const float* kr = kb + (long long)j * KV * hd;
+    float d = 0.f;
+    for (int e = 0; e < hd; ++e) d = __builtin_fmaf(q[e], kr[e], d);
+    d *= scale;
+    sc[j] = d;
+    mx = fmaxf(mx, d);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(red[0], red[1]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < nk; j += 128) {
+    const float p = expf(sc[j] - mx);
+    sc[j] = p;
+    sum += p;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1]);
+  for (int e = tid; e < hd; e += 128) {
+    float acc = 0.f;
+    for (int j = 0; j < nk; ++j) acc = __builtin_fmaf(sc[j], vb[(long long)j * KV * hd + e], acc);
+    out[((long long)b * S + s) * H * hd + h * hd + e] = acc * inv;
+  }
+}
+
+// silu(gate) * up, gu [rows][2I] -> [rows][I]
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* gu, int I, long long n, float* out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const long long r = e / I;
+  const int c = (int)(e - r * I);
+  const float g = gu[r * 2 * I + c], u = gu[r * 2 * I + I + c];
+  out[e] = (g / (1.0f + expf(-g))) * u;
+}
+
+// one workgroup per item: argmax (temp == 0 or no uniforms) or inverse CDF over the top_k logits in descending order
+// (ties: lower index first) of softmax(logit / temp) with the injected uniform u[b]
+__global__ __launch_bounds__(256) void sample_kernel(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out,
+                                                     int ostride) {
+  extern __shared__ float lg[];  // [V]
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  __shared__ float topv[64];
+  __shared__ int topi[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < V; j += 256) lg[j] = logits[(long long)b * V + j];
+  __syncthreads();
+  const bool greedy = u == nullptr || temp == 0.f;
+  const int k = greedy ? 1 : (top_k < 64 ? (top_k < V ? top_k : V) : 64);
+  for (int r = 0; r < k; ++r) {
+    float best = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = tid; j < V; j += 256) {
+      const float v = lg[j];
+      if (v > best) { best = v; bj = j; }
+    }
+    bv[tid] = best; bi[tid] = bj;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) {
+        const float v = bv[tid + st];
+        const int i = bi[tid + st];
+        if (v > bv[tid] || (v == bv[tid] && i < bi[tid])) { bv[tid] = v; bi[tid] = i; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      topv[r] = bv[0];
+      topi[r] = bi[0];
+      lg[bi[0]] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int pick = topi[0];
+    if (!greedy) {
+      float c[64];
+      const float z0 = topv[0] / temp;
+      float run = 0.f;
+      for (int r = 0; r < k; ++r) {
+        run += expf(topv[r] / temp - z0);
+        c[r] = run;
+      }
+      const float target = u[(long long)b * ustride] * run;
+      int j = 0;
+      while (j < k - 1 && c[j] < target) ++j;
+      pick = topi[j];
+    }
+    out[(long long)b * ostride] = pick;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------- host
+struct Packer {
+  kk_csm* m;
+  std::string err;
+  size_t alloc(size_t n) {
+    const size_t off = (m->pack.size() + 63) & ~(size_t)63;
+    m->pack.resize(off + n, 0.f);
+    return off;
+  }
+  const std::vector<float>* get(const std::string& name, size_t n) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) {
+      if (err.empty()) err = "missing parameter: " + name;
+      return nullptr;
+    }
+    if (it->second.size() != n) {
+      if (err.empty()) err = "unexpected size for " + name;
+      return nullptr;
+    }
+    return &it->second;
+  }
+  Vec vec(const std::string& name, size_t n) {
+    Vec r;
+    const std::vector<float>* v = get(name, n);
+    if (!v) return r;
+    r.n = n;
+    r.off = alloc(n);
+    memcpy(&m->pack[r.off], v->data(), n * 4);
+    m->host.erase(name);
+    return r;
+  }
+  // nn.Linear weights [O_i][I] stacked along the output axis -> one [I][ldw] pack; `transposed_src`: the source is [I][O] (audio_head)
+  Lin linear(const std::vector<std::string>& names, const std::vector<int>& outs, int I, const float* raw = nullptr) {
+    Lin l;
+    int O = 0;
+    for (int o : outs) O += o;
+    l.Cin = I; l.Cout = O; l.ldw = rup(O, 64);
+    l.off = alloc((size_t)I * l.ldw);
+    int base = 0;
+    for (size_t k = 0; k < outs.size(); ++k) {
+      const float* src = raw;
+      if (!raw) {
+        const std::vector<float>* w = get(names[k], (size_t)outs[k] * I);
+        if (!w) return l;
+        src = w->data();
+      }
+      float* dst = &m->pack[l.off];
+      if (raw) {  // [I][O]
+        for (int i = 0; i < I; ++i)
+          for (int o = 0; o < outs[k]; ++o) dst[(size_t)i * l.ldw + base + o] = src[(size_t)i * outs[k] + o];
+      } else {
+        for (int o = 0; o < outs[k]; ++o)
+          for (int i = 0; i < I; ++i) dst[(size_t)i * l.ldw + base + o] = src[(size_t)o * I + i];
+        m->host.erase(names[k]);
+      }
+      base += outs[k];
+    }
+    return l;
+  }
+};
+
+void llama3_theta(const kk_llama_args& a, std::vector<float>& th) {  // attention.py:33-82, float32 like the reference
+  const int half = a.head_dim / 2;
+  th.resize(half);
+  const double low_w = 8192.0 / 1.0, high_w = 8192.0 / 4.0;
+  for (int i = 0; i < half; ++i) {
+    const float f = 1.0f / powf(a.rope_theta, (float)(2 * i) / (float)a.head_dim);
+    const double wl = 2.0 * M_PI / (double)f;
+    double v;
+    if (wl < high_w) v = f;
+    else if (wl > low_w) v = (double)f / a.rope_factor;
+    else {
+      const double smooth = (8192.0 / wl - 1.0) / (4.0 - 1.0);
+      v = (1.0 - smooth) * (double)f / a.rope_factor + smooth * (double)f;
+    }
+    th[i] = (float)v;
+  }
+}
+
+void pack_stack(Packer& P, const std::string& name, Stack& st, int max_pos) {
+  const kk_llama_args& a = st.a;
+  const int H = a.num_heads, KV = a.num_kv_heads, hd = a.head_dim, D = a.hidden, I = a.intermediate;
+  st.layers.resize(a.num_layers);
+  for (int i = 0; i < a.num_layers; ++i) {
+    const std::string p = name + ".layers." + std::to_string(i);
+    LlamaLayer& L = st.layers[i];
+    L.n1 = P.vec(p + ".input_layernorm.weight", D);
+    L.n2 = P.vec(p + ".post_attention_layernorm.weight", D);
+    L.qkv = P.linear({p + ".self_attn.q_proj.weight", p + ".self_attn.k_proj.weight", p + ".self_attn.v_proj.weight"}, {H * hd, KV * hd, KV * hd}, D);
+    L.o = P.linear({p + ".self_attn.o_proj.weight"}, {D}, H * hd);
+    L.gu = P.linear({p + ".mlp.gate_proj.weight", p + ".mlp.up_proj.weight"}, {I, I}, D);
+    L.down = P.linear({p + ".mlp.down_proj.weight"}, {D}, I);
+  }
+  st.norm = P.vec(name + ".norm.weight", D);
+  std::vector<float> th;
+  llama3_theta(a, th);
+  st.max_pos = max_pos;
+  st.rope.n = (size_t)max_pos * (hd / 2) * 2;
+  st.rope.off = P.alloc(st.rope.n);
+  float* r = &P.m->pack[st.rope.off];
+  for (int pos = 0; pos < max_pos; ++pos)
+    for (int i = 0; i < hd / 2; ++i) {
+      const float ang = (float)pos * th[i];  // einsum in float32 (attention.py:56-58)
+      r[((size_t)pos * (hd / 2) + i) * 2] = cosf(ang);
+      r[((size_t)pos * (hd / 2) + i) * 2 + 1] = sinf(ang);
+    }
+}
+
+void resolve(kk_csm* m, Lin& l) { l.w = m->dev + l.off; }
+void resolve(kk_csm* m, Vec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
+void resolve(kk_csm* m, Stack& st) {
+  for (auto& L : st.layers) { resolve(m, L.qkv); resolve(m, L.o); resolve(m, L.gu); resolve(m, L.down); resolve(m, L.n1); resolve(m, L.n2); }
+  resolve(m, st.norm); resolve(m, st.rope);
+}
+
+struct Run {
+  kk_csm* m;
+  hipStream_t st;
+  int B;
+  char* base;
+  size_t cap, used;
+  bool dry, oom;
+  float* f32(size_t n) {
+    const size_t off = (used + 255) & ~(size_t)255;
+    used = off + n * 4;
+    if (dry) return nullptr;
+    if (used > cap) { oom = true; return nullptr; }
+    return (float*)(base + off);
+  }
+  // out[b][row][:] = W x[b][row][:] (+ res); x rows: `rows` per item at pitch `xbs` elements between items
+  int lin(const Lin& w, const float* x, long long xbs, int rows, float* out, long long obs, const float* res) {
+    if (dry) return 0;
+    KKConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.xbs = xbs; a.ldx = w.Cin; a.w = w.w; a.ldw = w.ldw;
+    a.out = out; a.obs = obs; a.ldo = w.Cout;
+    if (res) { a.res = res; a.rbs = obs; a.ldr = w.Cout; }
+    a.Cin = w.Cin; a.Cout = w.Cout; a.Kw = 1; a.mode = KK_CONV; a.stride = 1; a.dil = 1;
+    a.Q = rows; a.Lo_rows = rows; a.lin = KKLen{nullptr, 0, rows}; a.lout = KKLen{nullptr, 0, rows};
+    a.in_slope = 1.f; a.scale = 1.f;
+    return kk_launch_conv_generic(a, B, KK_F32, KK_F32, st);
+  }
+};
+
+#define CS_TRY(x)          \
+  do {                     \
+    const int rc__ = (x);  \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// h [B][S][D] (updated in place) -> out [B][S][D] = final norm; appends S positions to the stack's cache at st.offset
+int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
+  const kk_llama_args& a = st.a;
+  const int B = r.B, H = a.num_heads, KV = a.num_kv_heads, hd = a.head_dim, D = a.hidden, I = a.intermediate;
+  const int W = (H + 2 * KV) * hd;
+  float* x = r.f32((size_t)B * S * D);
+  float* qkv = r.f32((size_t)B * S * W);
+  float* att = r.f32((size_t)B * S * H * hd);
+  float* gu = r.f32((size_t)B * S * 2 * I);
+  float* act = r.f32((size_t)B * S * I);
+  if (r.oom) return kk_fail("kk_csm: workspace too small");
+  if (!r.dry && offset + S > st.max_pos) return kk_fail("kk_csm: sequence exceeds the cache (max_seq_len)");
+  for (int l = 0; l < a.num_layers; ++l) {
+    const LlamaLayer& L = st.layers[l];
+    float* kc = st.kc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
+    float* vc = st.vc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
+    if (!r.dry) {
+      hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, L.n1.p, D, a.rms_eps, x);
+      KK_CHECK_LAUNCH();
+    }
+    CS_TRY(r.lin(L.qkv, x, (long long)S * D, S, qkv, (long long)S * W, nullptr));
+    if (!r.dry) {
+      hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, offset, kc, vc, st.max_pos);
+      KK_CHECK_LAUNCH();
+      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), (size_t)(offset + S) * 4, r.st, qkv, S, H, KV, hd, offset, kc, vc, st.max_pos,
+                         1.0f / sqrtf((float)hd), att);
+      KK_CHECK_LAUNCH();
+    }
+    CS_TRY(r.lin(L.o, att, (long long)S * H * hd, S, h, (long long)S * D, h));
+    if (!r.dry) {
+      hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, L.n2.p, D, a.rms_eps, x);
+      KK_CHECK_LAUNCH();
+    }
+    CS_TRY(r.lin(L.gu, x, (long long)S * D, S, gu, (long long)S * 2 * I, nullptr));
+    if (!r.dry) {
+      const long long n = (long long)B * S * I;
+      hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, gu, I, n, act);
+      KK_CHECK_LAUNCH();
+    }
+    CS_TRY(r.lin(L.down, act, (long long)S * I, S, h, (long long)S * D, h));
+  }
+  if (!r.dry) {
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, st.norm.p, D, a.rms_eps, out);
+    KK_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, int top_k, const float* uniforms, int* codes) {
+  kk_csm* m = r.m;
+  const kk_csm_config& c = m->cfg;
+  const int B = r.B, ncb = c.audio_num_codebooks, V = c.audio_vocab_size, D = c.backbone.hidden, Dd = c.decoder.hidden;
+  const size_t mark = r.used;
+  float* h = r.f32((size_t)B * S * D);
+  float* hn = r.f32((size_t)B * S * D);
+  float* logits = r.f32((size_t)B * V);
+  float* curr = r.f32((size_t)B * 2 * D);
+  float* pin = r.f32((size_t)B * 2 * Dd);
+  float* dn = r.f32((size_t)B * 2 * Dd);
+  if (r.oom) return kk_fail("kk_csm_generate_frame: workspace too small");
+  if (!r.dry) {
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, D, h);
+    KK_CHECK_LAUNCH();
+  }
+  const size_t inner = r.used;
+  CS_TRY(stack_forward(r, m->bb, h, S, m->bb.offset, hn));
+  size_t peak = r.used;
+  r.used = inner;  // the stack's scratch is free again
+  const float* last_h = hn ? hn + (size_t)(S - 1) * D : nullptr;  // row S-1 of every item (pitch S*D)
+  CS_TRY(r.lin(m->c0_head, last_h, (long long)S * D, 1, logits, V, nullptr));
+  if (!r.dry) {
+    if (m->dbg_logits && hipMemcpyAsync(m->dbg_logits, logits, (size_t)B * V * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_csm: copy failed");
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), (size_t)V * 4, r.st, logits, V, temp, top_k, uniforms, ncb, codes, ncb);
+    KK_CHECK_LAUNCH();
+    // curr = [last_h, embed_audio(0, c0)]
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(B), dim3(256), 0, r.st, last_h, (long long)S * D, curr, (long long)2 * D, D);
+    KK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(embed_audio_kernel, dim3(B), dim3(256), 0, r.st, codes, ncb, m->audio_emb.p, 0, V, D, curr, 2, 1);
+    KK_CHECK_LAUNCH();
+  }
+  int rows = 2, dpos = 0;
+  for (int i = 1; i < ncb; ++i) {
+    r.used = inner;
+    CS_TRY(r.lin(m->proj, curr, (long long)rows * D, rows, pin, (long long)rows * Dd, nullptr));
+    CS_TRY(stack_forward(r, m->dec, pin, rows, dpos, dn));
+    if (r.used > peak) peak = r.used;
+    dpos += rows;
+    const float* dl = dn ? dn + (size_t)(rows - 1) * Dd : nullptr;
+    CS_TRY(r.lin(m->audio_head[i - 1], dl, (long long)rows * Dd, 1, logits, V, nullptr));
+    if (!r.dry) {
+      if (m->dbg_logits && hipMemcpyAsync(m->dbg_logits + (size_t)i * m->max_batch * V, logits, (size_t)B * V * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess)
+        return kk_fail("kk_csm: copy failed");
+      hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), (size_t)V * 4, r.st, logits, V, temp, top_k, uniforms ? uniforms + i : nullptr, ncb, codes + i, ncb);
+      KK_CHECK_LAUNCH();
+      hipLaunchKernelGGL(embed_audio_kernel, dim3(B), dim3(256), 0, r.st, codes + i, ncb, m->audio_emb.p, i, V, D, curr, 1, 0);
+      KK_CHECK_LAUNCH();
+    }
+    rows = 1;
+  }
+  r.used = peak;
+  (void)mark;
+  return 0;
+}
+
+int check_llama(const kk_llama_args& a) {
+  if (a.num_layers < 1 || a.num_heads < 1 || a.num_kv_heads < 1 || a.num_heads % a.num_kv_heads != 0) return kk_fail("kk_csm_create: bad head counts");
+  if (a.head_dim < 2 || (a.head_dim & 1) || a.hidden < 1 || a.intermediate < 1) return kk_fail("kk_csm_create: bad sizes");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int kk_csm_create(const kk_csm_config* cfg, kk_csm** out) {
+  if (!cfg || !out) return kk_fail("kk_csm_create: null argument");
+  if (cfg->audio_num_codebooks < 1 || cfg->audio_vocab_size < 1 || cfg->audio_vocab_size > 8192 || cfg->text_vocab_size < 1 || cfg->max_seq_len < 2)
+    return kk_fail("kk_csm_create: bad configuration");
+  CS_TRY(check_llama(cfg->backbone));
+  CS_TRY(check_llama(cfg->decoder));
+  kk_csm* m = new kk_csm();
+  m->cfg = *cfg;
+  m->bb.a = cfg->backbone;
+  m->dec.a = cfg->decoder;
+  *out = m;
+  return 0;
+}
+
+extern "C" void kk_csm_destroy(kk_csm* m) {
+  if (!m) return;
+  if (m->dev) (void)hipFree(m->dev);
+  for (Stack* s : {&m->bb, &m->dec}) {
+    if (s->kc) (void)hipFree(s->kc);
+    if (s->vc) (void)hipFree(s->vc);
+  }
+  if (m->dbg_logits) (void)hipFree(m->dbg_logits);
+  delete m;
+}
+
+extern "C" int kk_csm_load_tensor(kk_csm* m, const char* name, const int64_t* shape, int ndim, const float* data) {
+  if (!m || !name || !shape || !data || ndim < 1) return kk_fail("kk_csm_load_tensor: bad argument");
+  if (m->finalized) return kk_fail("kk_csm_load_tensor: model already finalized");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  m->host[name].assign(data, data + n);
+  return 0;
+}
+
+extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
+  if (!m) return kk_fail("kk_csm_finalize: null model");
+  if (m->finalized) return kk_fail("kk_csm_finalize: already finalized");
+  const kk_csm_config& c = m->cfg;
+  Packer P{m, ""};
+  const int D = c.backbone.hidden, Dd = c.decoder.hidden, V = c.audio_vocab_size, ncb = c.audio_num_codebooks;
+  pack_stack(P, "backbone", m->bb, c.max_seq_len);
+  pack_stack(P, "decoder", m->dec, ncb + 1);
+  m->text_emb = P.vec("text_embeddings.weight", (size_t)c.text_vocab_size * D);
+  m->audio_emb = P.vec("audio_embeddings.weight", (size_t)V * ncb * D);
+  m->proj = P.linear({"projection.weight"}, {Dd}, D);
+  m->c0_head = P.linear({"codebook0_head.weight"}, {V}, D);
+  m->audio_head.resize(ncb > 1 ? ncb - 1 : 0);
+  if (ncb > 1) {
+    const std::vector<float>* ah = P.get("audio_head", (size_t)(ncb - 1) * Dd * V);
+    if (ah)
+      for (int i = 0; i < ncb - 1; ++i) m->audio_head[i] = P.linear({}, {V}, Dd, ah->data() + (size_t)i * Dd * V);  // [Dd][V] used as x @ W
+  }
+  if (!P.err.empty()) return kk_fail(("kk_csm_finalize: " + P.err).c_str());
+  if (hipMalloc((void**)&m->dev, m->pack.size() * sizeof(float)) != hipSuccess) return kk_fail("kk_csm_finalize: hipMalloc failed");
+  if (hipMemcpyAsync(m->dev, m->pack.data(), m->pack.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+    return kk_fail("kk_csm_finalize: upload failed");
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: stream sync failed");
+  resolve(m, m->bb); resolve(m, m->dec); resolve(m, m->text_emb); resolve(m, m->audio_emb); resolve(m, m->proj); resolve(m, m->c0_head);
+  for (auto& l : m->audio_head) resolve(m, l);
+  m->host.clear();
+  std::vector<float>().swap(m->pack);
+  m->finalized = true;
+  return 0;
+}
+
+// SesameModel.setup_caches / reset_caches (sesame.py:320-345): device KV caches for `max_batch` items; positions restart at 0
+extern "C" int kk_csm_setup_caches(kk_csm* m, int max_batch) {
+  if (!m || !m->finalized || max_batch < 1) return kk_fail("kk_csm_setup_caches: bad argument");
+  for (Stack* s : {&m->bb, &m->dec}) {
+    if (s->kc) (void)hipFree(s->kc);
+    if (s->vc) (void)hipFree(s->vc);
+    s->kc = s->vc = nullptr;
+    const size_t n = (size_t)s->a.num_layers * max_batch * s->max_pos * s->a.num_kv_heads * s->a.head_dim * 4;
+    if (hipMalloc((void**)&s->kc, n) != hipSuccess || hipMalloc((void**)&s->vc, n) != hipSuccess) return kk_fail("kk_csm_setup_caches: hipMalloc failed");
+    s->offset = 0;
+  }
+  if (m->dbg_logits) (void)hipFree(m->dbg_logits);
+  m->dbg_logits = nullptr;
+  if (hipMalloc((void**)&m->dbg_logits, (size_t)m->cfg.audio_num_codebooks * max_batch * m->cfg.audio_vocab_size * 4) != hipSuccess)
+    return kk_fail("kk_csm_setup_caches: hipMalloc failed");
+  m->max_batch = max_batch;
+  return 0;
+}
+extern "C" int kk_csm_reset_caches(kk_csm* m) {
+  if (!m) return kk_fail("kk_csm_reset_caches: null model");
+  m->bb.offset = 0;
+  m->dec.offset = 0;
+  return 0;
+}
+extern "C" int kk_csm_position(const kk_csm* m) { return m ? m->bb.offset : -1; }
+
+extern "C" size_t kk_csm_workspace_bytes(kk_csm* m, int B, int S) {
+  if (!m || !m->finalized || B <= 0 || S <= 0) return 0;
+  Run r{m, nullptr, B, nullptr, 0, 0, true, false};
+  if (run_frame(r, S, nullptr, nullptr, 0.f, 1, nullptr, nullptr) != 0) return 0;
+  return r.used + 256;
+}
+
+extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, const int32_t* tokens, const float* tokens_mask, float temperature,
+                                     int top_k, const float* uniforms, void* workspace, size_t workspace_bytes, int32_t* codes_out) {
+  if (!m || !m->finalized) return kk_fail("kk_csm_generate_frame: model not finalized");
+  if (m->max_batch < 1) return kk_fail("kk_csm_generate_frame: call kk_csm_setup_caches first");
+  if (B <= 0 || B > m->max_batch || S <= 0 || !tokens || !tokens_mask || !workspace || !codes_out) return kk_fail("kk_csm_generate_frame: bad argument");
+  if (m->bb.offset + S > m->bb.max_pos) return kk_fail("kk_csm_generate_frame: sequence exceeds max_seq_len");
+  if (S > 1 && m->bb.offset != 0) return kk_fail("kk_csm_generate_frame: a multi-token block must start an empty cache (sesame.py:41-48)");
+  if (workspace_bytes < kk_csm_workspace_bytes(m, B, S)) return kk_fail("kk_csm_generate_frame: workspace too small");
+  Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
+  const int rc = run_frame(r, S, tokens, tokens_mask, temperature, top_k, uniforms, codes_out);
+  if (rc == 0) m->bb.offset += S;
+  return rc;
+}
+
+// logits of the last frame (tests): [n_cb][B][V] float32, device to device
+extern "C" int kk_csm_debug_logits(kk_csm* m, void* stream, int B, float* dst) {
+  if (!m || !m->dbg_logits || !dst || B < 1 || B > m->max_batch) return kk_fail("kk_csm_debug_logits: bad argument");
+  const int V = m->cfg.audio_vocab_size;
+  for (int i = 0; i < m->cfg.audio_num_codebooks; ++i)
+    if (hipMemcpyAsync(dst + (size_t)i * B * V, m->dbg_logits + (size_t)i * m->max_batch * V, (size_t)B * V * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+        hipSuccess)
+      return kk_fail("kk_csm_debug_logits: copy failed");
+  return 0;
+}

@@ -440,3 +440,61 @@ def mimi_synth_checkpoint(cfg: dict, seed: int = 0, encode: bool = False) -> dic
         if name.endswith("cluster_usage"):
             w[name.replace("cluster_usage", "embedding_sum")][:2] = 0.0  # ... without producing 1e5-scale rows
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CSM-1B frame generator (sesame.py:225-273 llama flavours, :276-415 SesameModel)
+# ---------------------------------------------------------------------------------------------------------------------
+def csm_config() -> dict:
+    rope = dict(rope_theta=500000.0, rope_factor=32.0, rms_eps=1e-5)
+    return dict(text_vocab_size=128256, audio_vocab_size=2051, audio_num_codebooks=32, max_seq_len=2048,
+                backbone=dict(num_layers=16, num_heads=32, num_kv_heads=8, head_dim=64, hidden=2048, intermediate=8192, **rope),
+                decoder=dict(num_layers=4, num_heads=8, num_kv_heads=2, head_dim=128, hidden=1024, intermediate=8192, **rope))
+
+
+def csm_tiny_config() -> dict:
+    rope = dict(rope_theta=500000.0, rope_factor=32.0, rms_eps=1e-5)
+    return dict(text_vocab_size=300, audio_vocab_size=67, audio_num_codebooks=4, max_seq_len=64,
+                backbone=dict(num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64, hidden=256, intermediate=512, **rope),
+                decoder=dict(num_layers=2, num_heads=2, num_kv_heads=1, head_dim=128, hidden=256, intermediate=384, **rope))
+
+
+def csm_param_inventory(cfg: dict) -> dict:
+    inv = {}
+    D, Dd = cfg["backbone"]["hidden"], cfg["decoder"]["hidden"]
+    for name, a in (("backbone", cfg["backbone"]), ("decoder", cfg["decoder"])):
+        H, KV, hd, Dm, I = a["num_heads"], a["num_kv_heads"], a["head_dim"], a["hidden"], a["intermediate"]
+        for i in range(a["num_layers"]):
+            p = f"{name}.layers.{i}"
+            inv[f"{p}.self_attn.q_proj.weight"] = (H * hd, Dm)
+            inv[f"{p}.self_attn.k_proj.weight"] = (KV * hd, Dm)
+            inv[f"{p}.self_attn.v_proj.weight"] = (KV * hd, Dm)
+            inv[f"{p}.self_attn.o_proj.weight"] = (Dm, H * hd)
+            inv[f"{p}.mlp.gate_proj.weight"] = (I, Dm)
+            inv[f"{p}.mlp.up_proj.weight"] = (I, Dm)
+            inv[f"{p}.mlp.down_proj.weight"] = (Dm, I)
+            inv[f"{p}.input_layernorm.weight"] = (Dm,)
+            inv[f"{p}.post_attention_layernorm.weight"] = (Dm,)
+        inv[f"{name}.norm.weight"] = (Dm,)
+    inv["text_embeddings.weight"] = (cfg["text_vocab_size"], D)
+    inv["audio_embeddings.weight"] = (cfg["audio_vocab_size"] * cfg["audio_num_codebooks"], D)
+    inv["projection.weight"] = (Dd, D)
+    inv["codebook0_head.weight"] = (cfg["audio_vocab_size"], D)
+    inv["audio_head"] = (cfg["audio_num_codebooks"] - 1, Dd, cfg["audio_vocab_size"])
+    return inv
+
+
+def csm_synth_checkpoint(cfg: dict, seed: int = 0) -> dict:
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in csm_param_inventory(cfg).items():
+        if name.endswith("layernorm.weight") or name.endswith("norm.weight"):
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif name.endswith("embeddings.weight"):
+            w[name] = rng.standard_normal(shape, dtype=np.float32)
+        elif name == "audio_head":
+            w[name] = (rng.standard_normal(shape, dtype=np.float32) * (3.0 / np.sqrt(shape[1]))).astype(np.float32)
+        else:
+            gain = 3.0 if name.startswith("codebook0_head") else (0.5 if ("o_proj" in name or "down_proj" in name) else 1.0)
+            w[name] = (rng.standard_normal(shape, dtype=np.float32) * (gain / np.sqrt(shape[-1]))).astype(np.float32)
+    return w
