@@ -243,6 +243,58 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int V,
   }
 }
 
+// Skinny GEMM for the single-token steps (M = B rows <= 16): out[m][n] = sum_k x[m][k] W[k][n].  HBM-bound on W, so the grid is
+// (N / 256 column blocks) x (KS slices of K): every thread streams ONE column of its K slice with coalesced row reads and keeps
+// M accumulators; the slices' partial sums are added in slice order by the second kernel (deterministic, residual fused).
+constexpr int SK_MAXM = 16, SK_KC = 256;
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* x, int M, int K, const float* w, int ldw, int N, int kchunk, float* part) {
+  __shared__ float xs[SK_MAXM][SK_KC];
+  const int n = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y;
+  const int k0 = ks * kchunk, k1 = min(K, k0 + kchunk);
+  float acc[SK_MAXM];
+#pragma unroll
+  for (int m = 0; m < SK_MAXM; ++m) acc[m] = 0.f;
+  for (int kb = k0; kb < k1; kb += SK_KC) {
+    const int kn = min(SK_KC, k1 - kb);
+    __syncthreads();
+    for (int e = threadIdx.x; e < M * kn; e += 256) {
+      const int m = e / kn, k = e - m * kn;
+      xs[m][k] = x[(long long)m * K + kb + k];
+    }
+    __syncthreads();
+    if (n < N) {
+      const float* wp = w + (long long)kb * ldw + n;
+      int k = 0;
+      for (; k + 16 <= kn; k += 16) {  // 16 independent loads in flight per thread: the kernel is latency-bound otherwise
+        float wv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wv[j] = wp[(long long)(k + j) * ldw];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+          for (int m = 0; m < SK_MAXM; ++m)
+            if (m < M) acc[m] = __builtin_fmaf(xs[m][k + j], wv[j], acc[m]);
+      }
+      for (; k < kn; ++k) {
+        const float wv = wp[(long long)k * ldw];
+#pragma unroll
+        for (int m = 0; m < SK_MAXM; ++m)
+          if (m < M) acc[m] = __builtin_fmaf(xs[m][k], wv, acc[m]);
+      }
+    }
+  }
+  if (n < N)
+    for (int m = 0; m < M; ++m) part[((long long)ks * M + m) * N + n] = acc[m];
+}
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, int KS, int M, int N, const float* res, float* out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)M * N) return;
+  float v = 0.f;
+  for (int ks = 0; ks < KS; ++ks) v += part[(long long)ks * M * N + e];
+  if (res) v += res[e];
+  out[e] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 struct Packer {
   kk_csm* m;
@@ -365,6 +417,8 @@ struct Run {
   char* base;
   size_t cap, used;
   bool dry, oom;
+  float* skinny_scratch = nullptr;  // partial sums of the skinny GEMM
+  size_t skinny_floats = 0;
   float* f32(size_t n) {
     const size_t off = (used + 255) & ~(size_t)255;
     used = off + n * 4;
@@ -383,7 +437,32 @@ struct Run {
     a.Cin = w.Cin; a.Cout = w.Cout; a.Kw = 1; a.mode = KK_CONV; a.stride = 1; a.dil = 1;
     a.Q = rows; a.Lo_rows = rows; a.lin = KKLen{nullptr, 0, rows}; a.lout = KKLen{nullptr, 0, rows};
     a.in_slope = 1.f; a.scale = 1.f;
-    return kk_launch_conv_generic(a, B, KK_F32, KK_F32, st);
+    int nb = B;
+    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && B * rows <= SK_MAXM && skinny_scratch) {
+      // single-token steps: the HBM-bound skinny GEMM (every CU streams a slice of W once for the whole batch)
+      const int M = B * rows, nblk = kk_cdiv(w.Cout, 256);
+      int KS = 1024 / nblk;
+      const int maxks = kk_cdiv(w.Cin, 32);
+      KS = KS < 1 ? 1 : (KS > maxks ? maxks : KS);
+      const int kchunk = kk_cdiv(kk_cdiv(w.Cin, KS), 32) * 32;
+      KS = kk_cdiv(w.Cin, kchunk);
+      if ((size_t)KS * M * w.Cout <= skinny_floats) {
+        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(nblk, KS), dim3(256), 0, st, x, M, w.Cin, w.w, w.ldw, w.Cout, kchunk, skinny_scratch);
+        KK_CHECK_LAUNCH();
+        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)(((long long)M * w.Cout + 255) / 256)), dim3(256), 0, st, skinny_scratch, KS, M, w.Cout, res, out);
+        KK_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout) {
+      // items are contiguous: one launch over B*rows rows, so a weight tile is read once for the whole batch (single-token steps would
+      // otherwise re-read every matrix once per item)
+      a.Q = a.Lo_rows = B * rows;
+      a.lin = a.lout = KKLen{nullptr, 0, B * rows};
+      a.xbs = a.obs = a.rbs = 0;
+      nb = 1;
+    }
+    return kk_launch_conv_generic(a, nb, KK_F32, KK_F32, st);
   }
 };
 
@@ -452,6 +531,10 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   float* curr = r.f32((size_t)B * 2 * D);
   float* pin = r.f32((size_t)B * 2 * Dd);
   float* dn = r.f32((size_t)B * 2 * Dd);
+  {  // skinny-GEMM partials: at most 1024 workgroups of 256 columns -> KS * N <= 1024 * 256 (+ slack for the rounding of the K slices)
+    r.skinny_floats = (size_t)2 * 1024 * 256 * (B < SK_MAXM ? B : SK_MAXM);
+    r.skinny_scratch = r.f32(r.skinny_floats);
+  }
   if (r.oom) return kk_fail("kk_csm_generate_frame: workspace too small");
   if (!r.dry) {
     hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, D, h);

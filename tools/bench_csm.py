@@ -1,0 +1,58 @@
+"""CSM-1B frame generation rate (config 4): B streams, one prompt block then N single-token frames; audio-seconds (80 ms per frame)
+per wall-second.  python tools/bench_csm.py [--batch 8] [--prompt 64] [--frames 10] [--layers 16]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mlx_audio_amd.params as P  # noqa: E402
+from mlx_audio_amd.csm import SesameModel  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--prompt", type=int, default=64)
+ap.add_argument("--frames", type=int, default=10)
+a = ap.parse_args()
+cfg = P.csm_config()
+t0 = time.time()
+w = P.csm_synth_checkpoint(cfg, 0)
+t1 = time.time()
+model = SesameModel(cfg, w)
+del w
+model.setup_caches(a.batch)
+t2 = time.time()
+rng = np.random.default_rng(0)
+n, B = cfg["audio_num_codebooks"], a.batch
+tok = np.zeros((B, a.prompt, n + 1), np.int64)
+msk = np.zeros((B, a.prompt, n + 1), np.float32)
+tok[:, :, -1] = rng.integers(0, cfg["text_vocab_size"], (B, a.prompt))
+msk[:, :, -1] = 1
+torch.cuda.synchronize()
+tp = time.perf_counter()
+codes = model.generate_frame(torch.tensor(tok), torch.tensor(msk), temperature=0.9, top_k=50, uniforms=torch.tensor(rng.uniform(size=(B, n)).astype(np.float32)))
+torch.cuda.synchronize()
+prefill_ms = (time.perf_counter() - tp) * 1e3
+step_tok = torch.zeros((B, 1, n + 1), dtype=torch.int32, device="cuda")
+step_msk = torch.zeros((B, 1, n + 1), dtype=torch.float32, device="cuda")
+step_msk[:, 0, :n] = 1
+us = torch.tensor(rng.uniform(size=(a.frames + 2, B, n)).astype(np.float32), device="cuda")
+for i in range(2):  # warm-up frames
+    step_tok[:, 0, :n] = codes
+    codes = model.generate_frame(step_tok, step_msk, temperature=0.9, top_k=50, uniforms=us[i])
+torch.cuda.synchronize()
+ts = time.perf_counter()
+for i in range(a.frames):
+    step_tok[:, 0, :n] = codes
+    codes = model.generate_frame(step_tok, step_msk, temperature=0.9, top_k=50, uniforms=us[2 + i])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - ts) / a.frames
+print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B frame generation (80 ms of audio per frame and stream), fp32", "value": B * 0.08 / dt,
+                  "ms_per_frame": dt * 1e3, "batch": B, "prompt_tokens": a.prompt, "prefill_ms": prefill_ms, "frames_timed": a.frames, "dtype": "f32",
+                  "data": "synthetic (random-init CSM-1B weights, random prompt, injected uniforms)",
+                  "setup_s": {"synth_checkpoint": round(t1 - t0, 1), "load_finalize": round(t2 - t1, 1)}}))
