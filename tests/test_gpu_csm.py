@@ -20,6 +20,12 @@ from _util import err_stats, report  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+def SesameModel_(cfg, w):
+    from mlx_audio_amd.csm import SesameModel
+
+    return SesameModel(cfg, w)
+
+
 def _prompt(cfg, rng, B, n_text, n_audio):
     n = cfg["audio_num_codebooks"]
     S = n_text + n_audio
@@ -98,3 +104,59 @@ def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     report("csm/realheads/logits", **e)
     assert e["rel_max"] < 2e-4, e
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
+    """Config-4 data flow on tiny models: reference audio -> Mimi.encode -> prompt frames (text ids | audio codes + EOS frame | text
+    ids) -> frame loop -> Mimi.decode -> waveform.  The same loop driven by the two CPU oracles gives the same codes."""
+    import mimi_oracle as MO
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+    from mlx_audio_amd.sesame import Model, Segment
+
+    ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
+    mcfg = P.mimi_tiny_config()  # nq 4, bins 64: matches the frame generator's code books
+    cw = P.csm_synth_checkpoint(ccfg, 3)
+    mw = P.mimi_synth_checkpoint(mcfg, 3, encode=True)
+    model = SesameModel_(ccfg, cw)
+    model.setup_caches(2)
+    mimi = Mimi(MimiConfig.from_dict(mcfg), mw)
+    loop = Model(model, mimi)
+    rng = np.random.default_rng(9)
+    ref_audio = [(0.3 * rng.standard_normal(1920 * 3)).astype(np.float32) for _ in range(2)]
+    ctx = [[Segment(speaker=0, text_ids=rng.integers(0, 300, 5).tolist(), audio=ref_audio[b])] for b in range(2)]
+    prompts = [rng.integers(0, 300, 4).tolist() for _ in range(2)]
+    res = loop.generate(ctx, prompts, max_audio_length_ms=80 * 6, temperature=0.0, stop_on_eos=False)
+    assert res.token_count == 6 and tuple(res.audio.shape) == (2, 6 * 1920) and bool(torch.isfinite(res.audio).all())
+    # oracle loop
+    morc = MO.MimiOracle(mw, mcfg)
+    corc = C.CsmOracle(cw, ccfg)
+    n = 4
+    toks, masks = [], []
+    for b in range(2):
+        codes = morc.encode(ref_audio[b][None, None])[0]
+        codes = np.concatenate([codes, np.zeros((n, 1), codes.dtype)], 1)
+        rows = []
+        for ids in (ctx[b][0].text_ids,):
+            f = np.zeros((len(ids), n + 1), np.int64); f[:, -1] = ids
+            m = np.zeros((len(ids), n + 1), np.float32); m[:, -1] = 1
+            rows.append((f, m))
+        f = np.zeros((codes.shape[1], n + 1), np.int64); f[:, :n] = codes.T
+        m = np.zeros((codes.shape[1], n + 1), np.float32); m[:, :n] = 1
+        rows.append((f, m))
+        f = np.zeros((len(prompts[b]), n + 1), np.int64); f[:, -1] = prompts[b]
+        m = np.zeros((len(prompts[b]), n + 1), np.float32); m[:, -1] = 1
+        rows.append((f, m))
+        toks.append(np.concatenate([r[0] for r in rows], 0))
+        masks.append(np.concatenate([r[1] for r in rows], 0))
+    t_in, m_in = np.stack(toks), np.stack(masks)
+    frames = []
+    for _ in range(6):
+        c = corc.generate_frame(t_in, m_in)
+        frames.append(c)
+        t_in = np.zeros((2, 1, n + 1), np.int64); t_in[:, 0, :n] = c
+        m_in = np.zeros((2, 1, n + 1), np.float32); m_in[:, 0, :n] = 1
+    ref_codes = np.stack(frames, 2)
+    ref_pcm = morc.decode(ref_codes)[:, 0]
+    e = err_stats(res.audio.cpu().numpy(), ref_pcm)
+    report("csm/e2e_tiny/pcm", **e)
+    assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
