@@ -243,6 +243,9 @@ size_t kk_csm_workspace_bytes(kk_csm* m, int B, int S);
  * make_sampler(temp, top_k) with a reproducible draw.  codes_out [B][n_cb] int32. */
 int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, const int32_t* tokens, const float* tokens_mask, float temperature, int top_k,
                           const float* uniforms, void* workspace, size_t workspace_bytes, int32_t* codes_out);
+/* graph replay of the single-token frame step: the third call with identical pointers / B / sampler settings and every later one is ONE
+ * hipGraphLaunch (the backbone position is a device counter, so the captured step is position-independent); results are unchanged */
+int kk_csm_set_graph_mode(kk_csm* m, int on);
 int kk_csm_debug_logits(kk_csm* m, void* stream, int B, float* dst); /* logits of the last frame, [n_cb][B][audio_vocab] */
 
 #ifdef __cplusplus

@@ -86,6 +86,7 @@ SIGNATURES = {
     "kk_csm_position": (_i, [_vp]),
     "kk_csm_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_csm_generate_frame": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _sz, _vp]),
+    "kk_csm_set_graph_mode": (_i, [_vp, _i]),
     "kk_csm_debug_logits": (_i, [_vp, _vp, _i, _vp]),
     "kk_mimi_create": (_i, [C.POINTER(KKMimiConfig), C.POINTER(_vp)]),
     "kk_mimi_destroy": (None, [_vp]),

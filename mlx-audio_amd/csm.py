@@ -39,6 +39,8 @@ class SesameModel:
         self._final = False
         self._ws = None
         self._enabled = False
+        self._graph = False
+        self._gbuf = {}
         if weights is not None:
             self.load_weights(weights)
 
@@ -75,6 +77,12 @@ class SesameModel:
     def reset_caches(self) -> None:
         check(self.lib.kk_csm_reset_caches(self._h), "kk_csm_reset_caches")
 
+    def set_graph_mode(self, on: bool = True) -> None:
+        """kk_csm_set_graph_mode: single-token frames are replayed as one hipGraph.  Inputs are staged in buffers that persist across
+        calls (a graph is keyed on its pointers); the returned codes are a view that the next frame overwrites."""
+        check(self.lib.kk_csm_set_graph_mode(self._h, 1 if on else 0), "kk_csm_set_graph_mode")
+        self._graph = bool(on)
+
     @property
     def position(self) -> int:
         return int(self.lib.kk_csm_position(self._h))
@@ -99,13 +107,25 @@ class SesameModel:
             u = torch.as_tensor(uniforms).to(device=self.device, dtype=torch.float32).contiguous()
             if tuple(u.shape) != (B, ncb):
                 raise ValueError(f"uniforms must be [B, {ncb}]")
+        if self._graph and S == 1:
+            key = (B, u is not None)
+            if key not in self._gbuf:
+                self._gbuf[key] = (torch.empty_like(tokens), torch.empty_like(mask), torch.empty((B, ncb), dtype=torch.float32, device=self.device),
+                                   torch.empty((B, ncb), dtype=torch.int32, device=self.device))
+            gt, gm, gu, gc = self._gbuf[key]
+            gt.copy_(tokens)
+            gm.copy_(mask)
+            if u is not None:
+                gu.copy_(u)
+                u = gu
+            tokens, mask = gt, gm
         with torch.cuda.device(self.device):
             need = int(self.lib.kk_csm_workspace_bytes(self._h, B, S))
             if need == 0:
                 raise KokoroHipError("kk_csm_workspace_bytes failed")
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            codes = torch.empty((B, ncb), dtype=torch.int32, device=self.device)
+            codes = self._gbuf[(B, u is not None)][3] if (self._graph and S == 1) else torch.empty((B, ncb), dtype=torch.int32, device=self.device)
             check(self.lib.kk_csm_generate_frame(self._h, self._stream(), B, S, C.c_void_p(tokens.data_ptr()), C.c_void_p(mask.data_ptr()),
                                                  float(temperature), int(top_k), C.c_void_p(u.data_ptr()) if u is not None else None,
                                                  C.c_void_p(self._ws.data_ptr()), need, C.c_void_p(codes.data_ptr())), "kk_csm_generate_frame")

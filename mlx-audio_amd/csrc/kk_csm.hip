@@ -42,6 +42,7 @@ struct Stack {
   float* kc = nullptr;  // [layers][maxB][max_pos][KV*hd]
   float* vc = nullptr;
   int max_pos = 0, offset = 0;
+  int* pos_dev = nullptr;  // backbone only: device copy of `offset` (null: positions are launch constants)
 };
 
 }  // namespace
@@ -58,6 +59,16 @@ struct kk_csm {
   std::vector<Lin> audio_head;
   int max_batch = 0;
   float* dbg_logits = nullptr;  // [n_cb][maxB][V] of the last frame
+  // graph replay of the single-token frame step (kk_csm_set_graph_mode)
+  struct GraphEntry {
+    std::vector<unsigned long long> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;
+  };
+  bool graph_mode = false;
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;
 };
 
 namespace {
@@ -110,9 +121,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const floa
 }
 
 // RoPE on q (in place) and k, then k / v of the new rows go into the cache at [offset + s]
-__global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int H, int KV, int hd, const float* rope, int offset, float* kc, float* vc,
-                                                          int max_pos) {
+__global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int H, int KV, int hd, const float* rope, const int* pos_dev, int offset,
+                                                          float* kc, float* vc, int max_pos) {
   const int s = blockIdx.x, b = blockIdx.y;
+  if (pos_dev) offset += *pos_dev;  // the backbone's position lives in device memory so that a captured frame step can be replayed
   const int W = (H + 2 * KV) * hd, half = hd / 2;
   float* row = qkv + ((long long)b * S + s) * W;
   const float* cs = rope + (long long)(offset + s) * half * 2;
@@ -136,10 +148,11 @@ __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int
 }
 
 // one workgroup per (query s, head h, item b): scores over the cached keys 0 .. offset+s, softmax, weighted sum of V
-__global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, int offset, const float* kc, const float* vc,
-                                                         int max_pos, float scale, float* out) {
-  extern __shared__ float sc[];  // [nkeys]
+__global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, const float* kc,
+                                                         const float* vc, int max_pos, float scale, float* out) {
+  extern __shared__ float sc[];  // [max_pos]
   __shared__ float red[2];
+  if (pos_dev) offset += *pos_dev;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = offset + s + 1;
   const float* q = qkv + ((long long)b * S + s) * W + h * hd;
@@ -175,6 +188,8 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
     out[((long long)b * S + s) * H * hd + h * hd + e] = acc * inv;
   }
 }
+
+__global__ void advance_pos_kernel(int* pos, int by) { *pos += by; }
 
 // silu(gate) * up, gu [rows][2I] -> [rows][I]
 __global__ __launch_bounds__(256) void swiglu_kernel(const float* gu, int I, long long n, float* out) {
@@ -284,13 +299,21 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* x, int M,
     }
   }
   if (n < N)
-    for (int m = 0; m < M; ++m) part[((long long)ks * M + m) * N + n] = acc[m];
+    for (int m = 0; m < M; ++m) part[((long long)m * N + n) * gridDim.y + ks] = acc[m];  // slices of one output element are contiguous
 }
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, int KS, int M, int N, const float* res, float* out) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)M * N) return;
+  const float* p = part + e * KS;
   float v = 0.f;
-  for (int ks = 0; ks < KS; ++ks) v += part[(long long)ks * M * N + e];
+  int ks = 0;
+  if ((KS & 3) == 0) {
+    for (; ks < KS; ks += 4) {
+      const float4 q = *(const float4*)(p + ks);
+      v += q.x; v += q.y; v += q.z; v += q.w;  // slice order
+    }
+  }
+  for (; ks < KS; ++ks) v += p[ks];
   if (res) v += res[e];
   out[e] = v;
 }
@@ -441,8 +464,9 @@ struct Run {
     if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && B * rows <= SK_MAXM && skinny_scratch) {
       // single-token steps: the HBM-bound skinny GEMM (every CU streams a slice of W once for the whole batch)
       const int M = B * rows, nblk = kk_cdiv(w.Cout, 256);
-      int KS = 1024 / nblk;
-      const int maxks = kk_cdiv(w.Cin, 32);
+      int KS = 1024 / nblk;  // ~4 workgroups per CU (measured: fewer, longer slices are slower -- the kernel is latency-bound)
+      int maxks = kk_cdiv(w.Cin, 32);
+      if (maxks > 64) maxks = 64;
       KS = KS < 1 ? 1 : (KS > maxks ? maxks : KS);
       const int kchunk = kk_cdiv(kk_cdiv(w.Cin, KS), 32) * 32;
       KS = kk_cdiv(w.Cin, kchunk);
@@ -494,10 +518,10 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
     }
     CS_TRY(r.lin(L.qkv, x, (long long)S * D, S, qkv, (long long)S * W, nullptr));
     if (!r.dry) {
-      hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, offset, kc, vc, st.max_pos);
+      hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
       KK_CHECK_LAUNCH();
-      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), (size_t)(offset + S) * 4, r.st, qkv, S, H, KV, hd, offset, kc, vc, st.max_pos,
-                         1.0f / sqrtf((float)hd), att);
+      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), (size_t)st.max_pos * 4, r.st, qkv, S, H, KV, hd, st.pos_dev, st.pos_dev ? 0 : offset, kc,
+                         vc, st.max_pos, 1.0f / sqrtf((float)hd), att);
       KK_CHECK_LAUNCH();
     }
     CS_TRY(r.lin(L.o, att, (long long)S * H * hd, S, h, (long long)S * D, h));
@@ -575,6 +599,10 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
     }
     rows = 1;
   }
+  if (!r.dry) {
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, r.st, m->bb.pos_dev, S);
+    KK_CHECK_LAUNCH();
+  }
   r.used = peak;
   (void)mark;
   return 0;
@@ -610,6 +638,12 @@ extern "C" void kk_csm_destroy(kk_csm* m) {
     if (s->vc) (void)hipFree(s->vc);
   }
   if (m->dbg_logits) (void)hipFree(m->dbg_logits);
+  if (m->bb.pos_dev) (void)hipFree(m->bb.pos_dev);
+  for (auto& g : m->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   delete m;
 }
 
@@ -668,6 +702,8 @@ extern "C" int kk_csm_setup_caches(kk_csm* m, int max_batch) {
   m->dbg_logits = nullptr;
   if (hipMalloc((void**)&m->dbg_logits, (size_t)m->cfg.audio_num_codebooks * max_batch * m->cfg.audio_vocab_size * 4) != hipSuccess)
     return kk_fail("kk_csm_setup_caches: hipMalloc failed");
+  if (!m->bb.pos_dev && hipMalloc((void**)&m->bb.pos_dev, 4) != hipSuccess) return kk_fail("kk_csm_setup_caches: hipMalloc failed");
+  if (hipMemset(m->bb.pos_dev, 0, 4) != hipSuccess) return kk_fail("kk_csm_setup_caches: memset failed");
   m->max_batch = max_batch;
   return 0;
 }
@@ -675,6 +711,7 @@ extern "C" int kk_csm_reset_caches(kk_csm* m) {
   if (!m) return kk_fail("kk_csm_reset_caches: null model");
   m->bb.offset = 0;
   m->dec.offset = 0;
+  if (m->bb.pos_dev && hipMemset(m->bb.pos_dev, 0, 4) != hipSuccess) return kk_fail("kk_csm_reset_caches: memset failed");
   return 0;
 }
 extern "C" int kk_csm_position(const kk_csm* m) { return m ? m->bb.offset : -1; }
@@ -694,10 +731,69 @@ extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, cons
   if (m->bb.offset + S > m->bb.max_pos) return kk_fail("kk_csm_generate_frame: sequence exceeds max_seq_len");
   if (S > 1 && m->bb.offset != 0) return kk_fail("kk_csm_generate_frame: a multi-token block must start an empty cache (sesame.py:41-48)");
   if (workspace_bytes < kk_csm_workspace_bytes(m, B, S)) return kk_fail("kk_csm_generate_frame: workspace too small");
-  Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
-  const int rc = run_frame(r, S, tokens, tokens_mask, temperature, top_k, uniforms, codes_out);
+  auto eager = [&](void* on_stream) -> int {
+    Run r{m, (hipStream_t)on_stream, B, (char*)workspace, workspace_bytes, 0, false, false};
+    return run_frame(r, S, tokens, tokens_mask, temperature, top_k, uniforms, codes_out);
+  };
+  int rc;
+  if (!m->graph_mode || S != 1) {
+    rc = eager(stream);
+  } else {
+    // the single-token step (~1400 launches) as one hipGraphLaunch: every position-dependent kernel reads the device counter
+    unsigned tbits;
+    memcpy(&tbits, &temperature, 4);
+    const std::vector<unsigned long long> key = {(unsigned long long)B, (unsigned long long)(uintptr_t)tokens, (unsigned long long)(uintptr_t)tokens_mask,
+        (unsigned long long)tbits, (unsigned long long)top_k, (unsigned long long)(uintptr_t)uniforms, (unsigned long long)(uintptr_t)workspace,
+        (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)codes_out};
+    kk_csm::GraphEntry* ge = nullptr;
+    for (auto& g : m->graphs)
+      if (g.key == key) ge = &g;
+    if (!ge) {
+      if (m->graphs.size() >= 8) {
+        if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
+        if (m->graphs.front().graph) (void)hipGraphDestroy(m->graphs.front().graph);
+        m->graphs.erase(m->graphs.begin());
+      }
+      m->graphs.emplace_back();
+      ge = &m->graphs.back();
+      ge->key = key;
+    }
+    if (ge->seen == 0) {
+      ge->seen = 1;
+      rc = eager(stream);
+    } else {
+      rc = 0;
+      if (ge->seen == 1) {
+        if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) return kk_fail("kk_csm: hipStreamCreate failed");
+        if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return kk_fail("kk_csm: hipStreamBeginCapture failed");
+        rc = eager((void*)m->cap_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+        if (rc != 0) {
+          if (g) (void)hipGraphDestroy(g);
+          return rc;
+        }
+        if (e != hipSuccess || !g) return kk_fail("kk_csm: hipStreamEndCapture failed");
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+          (void)hipGraphDestroy(g);
+          return kk_fail("kk_csm: hipGraphInstantiate failed");
+        }
+        ge->graph = g;
+        ge->exec = ex;
+        ge->seen = 2;
+      }
+      if (hipGraphLaunch(ge->exec, (hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm: hipGraphLaunch failed");
+    }
+  }
   if (rc == 0) m->bb.offset += S;
   return rc;
+}
+
+extern "C" int kk_csm_set_graph_mode(kk_csm* m, int on) {
+  if (!m) return kk_fail("kk_csm_set_graph_mode: null model");
+  m->graph_mode = on != 0;
+  return 0;
 }
 
 // logits of the last frame (tests): [n_cb][B][V] float32, device to device

@@ -95,6 +95,7 @@ class Model:
             raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_seq_len}")  # sesame.py:755-758
         dev = self.model.device
         self.model.reset_caches()
+        self.model.set_graph_mode(True)  # the frame steps after the prompt block are replayed as one hipGraph
         curr = torch.tensor(np.stack(toks), device=dev)
         cmask = torch.tensor(np.stack(masks), device=dev)
         rng = np.random.default_rng(seed) if seed is not None else None
@@ -109,7 +110,7 @@ class Model:
                 done |= (sample == 0).all(dim=1)  # an all-zero frame is EOS (sesame.py:765-766)
                 if bool(done.all()):
                     break
-            samples.append(sample)
+            samples.append(sample.clone())  # (graph replay hands back a view of a persistent buffer)
             curr = torch.zeros((B, 1, self.n_cb + 1), dtype=torch.int32, device=dev)
             curr[:, 0, : self.n_cb] = sample
             cmask = step_mask

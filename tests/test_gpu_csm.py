@@ -82,6 +82,34 @@ def test_csm_tiny_frames_match_oracle():
         model.generate_frame(torch.tensor(tok), torch.tensor(msk))
 
 
+def test_csm_graph_replay_gives_the_same_codes():
+    """kk_csm_set_graph_mode: eager, captured and replayed single-token frames produce the codes of the eager run."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_tiny_config()
+    w = P.csm_synth_checkpoint(cfg, 4)
+    rng = np.random.default_rng(17)
+    B, n = 2, cfg["audio_num_codebooks"]
+    tok, msk = _prompt(cfg, rng, B, 4, 2)
+    us = rng.uniform(size=(7, B, n)).astype(np.float32)
+
+    def run(graph):
+        model = SesameModel(cfg, w)
+        model.setup_caches(B)
+        model.set_graph_mode(graph)
+        out = [model.generate_frame(torch.tensor(tok), torch.tensor(msk)).cpu().numpy().copy()]
+        for i in range(7):
+            t_in = np.zeros((B, 1, n + 1), np.int64)
+            t_in[:, 0, :n] = out[-1]
+            m_in = np.zeros((B, 1, n + 1), np.float32)
+            m_in[:, 0, :n] = 1
+            out.append(model.generate_frame(torch.tensor(t_in), torch.tensor(m_in), temperature=0.8, top_k=20, uniforms=torch.tensor(us[i])).cpu().numpy().copy())
+        assert model.position == tok.shape[1] + 7
+        return np.stack(out)
+
+    np.testing.assert_array_equal(run(True), run(False))
+
+
 def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     """llama-1B / llama-100M head geometry (32 q / 8 kv heads of 64; 8 q / 2 kv heads of 128) with 2 layers each and small vocabularies."""
     from mlx_audio_amd.csm import SesameModel
