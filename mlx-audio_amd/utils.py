@@ -79,6 +79,16 @@ def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtyp
 
         any_bf16 = any(getattr(v, "dtype", None) == torch.bfloat16 for v in weights.values())
         compute_dtype = "bfloat16" if any_bf16 else "float32"  # the checkpoint dtype decides, as in the reference
+    quantization = config.get("quantization", None)
+    if quantization is not None:  # utils.py:241-260: MLX affine group quantisation -> dequantised here, see quant.py
+        import numpy as np
+        import torch
+
+        from .quant import dequantize_checkpoint
+
+        as_np = {k: (v.float().numpy() if isinstance(v, torch.Tensor) and v.dtype in (torch.bfloat16, torch.float16) else
+                     (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))) for k, v in weights.items()}
+        weights = dequantize_checkpoint(as_np, int(quantization["group_size"]), int(quantization["bits"]))
     cfg = arch.ModelConfig.from_dict(config)
     model = arch.Model(cfg, compute_dtype=compute_dtype)
     model.load_weights(weights, strict=strict)

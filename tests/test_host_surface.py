@@ -156,3 +156,26 @@ def test_load_model_error_behaviour(tmp_path):
         load_model(str(d2))  # unsupported model type (utils.py:116-119)
     with pytest.raises(ValueError):
         load_model(123)
+
+
+def test_mlx_affine_quantisation_round_trip():
+    """quant.py (row Q1, loader level): pack / unpack are inverse, the dequantised matrix is within half a step of the original,
+    and dequantize_checkpoint applies the reference's predicate ({p}.scales present, utils.py:243-252)."""
+    from mlx_audio_amd.quant import dequantize_affine, dequantize_checkpoint, quantize_affine
+
+    rng = np.random.default_rng(0)
+    for bits in (8, 4):
+        w = rng.standard_normal((24, 256)).astype(np.float32)
+        words, scales, biases = quantize_affine(w, 64, bits)
+        assert words.dtype == np.uint32 and words.shape == (24, 256 * bits // 32) and scales.shape == biases.shape == (24, 4)
+        back = dequantize_affine(words, scales, biases, 64, bits)
+        assert np.all(np.abs(back - w) <= 0.5 * np.repeat(scales, 64, axis=1) + 1e-6)
+        w2, s2, b2 = quantize_affine(back, 64, bits)  # a dequantised matrix is a fixed point of the quantiser's grid
+        np.testing.assert_allclose(dequantize_affine(w2, s2, b2, 64, bits), back, atol=2e-6)
+    # first element of a word sits in the least significant bits
+    words, scales, biases = quantize_affine(np.tile(np.arange(64, dtype=np.float32), (1, 1)), 64, 8)
+    assert int(words[0, 0] & 0xFF) == 0 and int((words[0, 0] >> 8) & 0xFF) == round(1 / scales[0, 0])
+    ck = {"a.weight": words, "a.scales": scales, "a.biases": biases, "b.weight": np.ones((2, 2), np.float32), "c.bias": np.zeros(3, np.float32)}
+    out = dequantize_checkpoint(ck, 64, 8)
+    assert set(out) == {"a.weight", "b.weight", "c.bias"} and out["a.weight"].shape == (1, 64) and out["a.weight"].dtype == np.float32
+    np.testing.assert_allclose(out["a.weight"][0], np.arange(64), atol=0.5 * float(scales[0, 0]) + 1e-5)
