@@ -499,6 +499,40 @@ def test_conv_mfma_bf16(lib, mfma4, case):
     assert e["rel_max"] < 5e-3  # one bf16 rounding of the result (2^-9 relative)
 
 
+def test_conv_mfma_random_shape_sweep(lib, mfma4):
+    """Seeded sweep over channel counts (pad channels, Cout not a multiple of 128), taps, dilations (halo up to the kernel's limit of 50),
+    lengths around the tile edges (191 / 192 / 193 / 385 rows) and ragged batches: the MFMA kernels against torch on the same bf16 operands."""
+    rng = np.random.default_rng(2024)
+    cins = [16, 24, 64, 72, 128, 200, 514]
+    couts = [16, 40, 64, 128, 136, 256]
+    taps = [(1, 1), (3, 1), (3, 5), (5, 2), (7, 3), (11, 5), (2, 1), (4, 7)]
+    lengths = [1, 5, 63, 191, 192, 193, 385, 600]
+    for case in range(14):
+        Cin, Cout = int(rng.choice(cins)), int(rng.choice(couts))
+        K, d = taps[int(rng.integers(len(taps)))]
+        L = int(rng.choice(lengths))
+        B = int(rng.integers(1, 4))
+        pad = int(rng.integers(0, (K - 1) * d + 1))  # any left padding, symmetric or not (causal = (K-1)*d)
+        lens = [L] + [int(rng.integers(1, L + 1)) for _ in range(B - 1)]
+        x = _bf(rng.standard_normal((B, L, Cin)).astype(np.float32))
+        for b, n in enumerate(lens):
+            x[b, n:] = 0
+        w = _bf((rng.standard_normal((Cout, K, Cin)) / math.sqrt(K * Cin)).astype(np.float32))
+        bias = rng.standard_normal(Cout).astype(np.float32)
+        use_res = bool(rng.integers(2))
+        res = _bf(rng.standard_normal((B, L, Cout)).astype(np.float32)) if use_res else None
+        got = run_conv_bf16(lib, x, w, bias, pad=pad, dil=d, res=res, Lout=L, lin=lens, lout=lens)
+        for b, n in enumerate(lens):
+            xp = F.pad(torch.tensor(x[b, :n])[None].transpose(1, 2), (pad, (K - 1) * d - pad))
+            ref = F.conv1d(xp, torch.tensor(w).permute(0, 2, 1), torch.tensor(bias), 1, 0, d).transpose(1, 2)[0].numpy()
+            if use_res:
+                ref = ref + res[b, :n]
+            e = err_stats(got[b, :n], ref)
+            report(f"conv_mfma{4 if mfma4 else 2}/sweep{case}_cin{Cin}_cout{Cout}_k{K}d{d}_L{L}/b{b}", **e)
+            assert e["max_abs"] < 6e-3 * max(1.0, e["ref_max"]), (case, Cin, Cout, K, d, L, pad, lens, e)
+            assert np.all(got[b, n:] == 0)
+
+
 def test_conv_mfma_epilogue_and_ragged(lib, mfma4):
     rng = np.random.default_rng(33)
     B, L, C, K, d = 3, 300, 128, 7, 3
