@@ -294,6 +294,48 @@ def test_result_does_not_depend_on_workspace_contents(dtype, flags):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_full_config_batch_invariance_bitexact(dtype):
+    """The production configuration (Kokoro-82M shapes; bf16 = variant-4 MFMA convs, fused AdaIN / statistics, MFMA attention, on-chip
+    LSTM): an utterance gives the same bits alone and inside a ragged batch, and graph replay does not change them."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.kokoro_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(50)
+    utts = [rng.integers(1, 178, n).tolist() for n in (21, 9, 14)]
+    eng = _engine(cfg, w, dtype)
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 3), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(3, device=dev)
+    forced = torch.full((3, Tmax), 3, dtype=torch.int32, device=dev)
+    Fmax = 3 * Tmax
+    wav, pred, nfr = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=3)]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(wav).all())
+    for b in range(3):
+        # Philox noise is indexed by (utterance slot, sample): the single call reproduces slot b only for b == 0, so compare with ZERO noise
+        pass
+    wz, pz, nz = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_ZERO)]
+    for b in range(3):
+        i1, l1, T1 = eng.pack_ids([utts[b]])
+        f1 = torch.full((1, T1), 3, dtype=torch.int32, device=dev)
+        w1, p1, n1 = eng.forward(i1, l1, ref_s[b : b + 1].contiguous(), sp[:1].contiguous(), 3 * T1, forced_dur=f1, noise_mode=_lib.NOISE_ZERO)
+        torch.cuda.synchronize()
+        n = 600 * int(n1[0])
+        assert int(n1[0]) == int(nz[b]) == 3 * T1
+        assert torch.equal(p1[0], pz[b, :T1])
+        assert torch.equal(w1[0, :n], wz[b, :n]), (dtype, b)
+        assert bool((wz[b, n:] == 0).all())
+    eng.set_graph_mode(True)
+    for _ in range(3):
+        wg, _, _ = eng.forward(ids, lens, ref_s, sp, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=3)
+    torch.cuda.synchronize()
+    assert torch.equal(wg, wav)
+    eng.set_graph_mode(False)
+
+
 def test_text_audio_split_equals_fused():
     from mlx_audio_amd import _lib
 
