@@ -461,20 +461,25 @@ struct Run {
     a.Q = rows; a.Lo_rows = rows; a.lin = KKLen{nullptr, 0, rows}; a.lout = KKLen{nullptr, 0, rows};
     a.in_slope = 1.f; a.scale = 1.f;
     int nb = B;
-    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && B * rows <= SK_MAXM && skinny_scratch) {
-      // single-token steps: the HBM-bound skinny GEMM (every CU streams a slice of W once for the whole batch)
-      const int M = B * rows, nblk = kk_cdiv(w.Cout, 256);
+    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && rows <= 2 && skinny_scratch) {
+      // single-token steps (and the decoder's 2-token first step): the HBM-bound skinny GEMM (every CU streams a slice of W once for up
+      // to 16 rows).  The choice depends on the rows PER ITEM only, never on B, so a stream's bits do not depend on its batch.
+      const int Mtot = B * rows, nblk = kk_cdiv(w.Cout, 256);
       int KS = 1024 / nblk;  // ~4 workgroups per CU (measured: fewer, longer slices are slower -- the kernel is latency-bound)
       int maxks = kk_cdiv(w.Cin, 32);
       if (maxks > 64) maxks = 64;
       KS = KS < 1 ? 1 : (KS > maxks ? maxks : KS);
       const int kchunk = kk_cdiv(kk_cdiv(w.Cin, KS), 32) * 32;
       KS = kk_cdiv(w.Cin, kchunk);
-      if ((size_t)KS * M * w.Cout <= skinny_floats) {
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(nblk, KS), dim3(256), 0, st, x, M, w.Cin, w.w, w.ldw, w.Cout, kchunk, skinny_scratch);
-        KK_CHECK_LAUNCH();
-        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)(((long long)M * w.Cout + 255) / 256)), dim3(256), 0, st, skinny_scratch, KS, M, w.Cout, res, out);
-        KK_CHECK_LAUNCH();
+      if ((size_t)KS * SK_MAXM * w.Cout <= skinny_floats) {
+        for (int m0 = 0; m0 < Mtot; m0 += SK_MAXM) {
+          const int M = Mtot - m0 < SK_MAXM ? Mtot - m0 : SK_MAXM;
+          hipLaunchKernelGGL(skinny_gemm_kernel, dim3(nblk, KS), dim3(256), 0, st, x + (size_t)m0 * w.Cin, M, w.Cin, w.w, w.ldw, w.Cout, kchunk, skinny_scratch);
+          KK_CHECK_LAUNCH();
+          hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)(((long long)M * w.Cout + 255) / 256)), dim3(256), 0, st, skinny_scratch, KS, M, w.Cout,
+                             res ? res + (size_t)m0 * w.Cout : nullptr, out + (size_t)m0 * w.Cout);
+          KK_CHECK_LAUNCH();
+        }
         return 0;
       }
     }
@@ -556,7 +561,7 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   float* pin = r.f32((size_t)B * 2 * Dd);
   float* dn = r.f32((size_t)B * 2 * Dd);
   {  // skinny-GEMM partials: at most 1024 workgroups of 256 columns -> KS * N <= 1024 * 256 (+ slack for the rounding of the K slices)
-    r.skinny_floats = (size_t)2 * 1024 * 256 * (B < SK_MAXM ? B : SK_MAXM);
+    r.skinny_floats = (size_t)2 * 1024 * 256 * SK_MAXM;
     r.skinny_scratch = r.f32(r.skinny_floats);
   }
   if (r.oom) return kk_fail("kk_csm_generate_frame: workspace too small");

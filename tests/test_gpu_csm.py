@@ -82,6 +82,36 @@ def test_csm_tiny_frames_match_oracle():
         model.generate_frame(torch.tensor(tok), torch.tensor(msk))
 
 
+def test_csm_streams_are_independent_bitexact():
+    """A stream produces the same logits alone (B = 1) and next to others (B = 3), prompt block and single-token frames."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_tiny_config()
+    w = P.csm_synth_checkpoint(cfg, 5)
+    rng = np.random.default_rng(27)
+    n = cfg["audio_num_codebooks"]
+    tok, msk = _prompt(cfg, rng, 3, 6, 2)
+
+    def run(sel):
+        model = SesameModel(cfg, w)
+        model.setup_caches(len(sel))
+        outs = []
+        c = model.generate_frame(torch.tensor(tok[sel]), torch.tensor(msk[sel]))
+        outs.append(model.debug_logits().cpu().numpy().copy())
+        for _ in range(3):
+            t_in = torch.zeros((len(sel), 1, n + 1), dtype=torch.int32)
+            t_in[:, 0, :n] = c.cpu()
+            m_in = torch.zeros((len(sel), 1, n + 1))
+            m_in[:, 0, :n] = 1
+            c = model.generate_frame(t_in, m_in)
+            outs.append(model.debug_logits().cpu().numpy().copy())
+        return np.stack(outs)  # [frames][n_cb][B][V]
+
+    full = run([0, 1, 2])
+    for b in range(3):
+        np.testing.assert_array_equal(run([b])[:, :, 0], full[:, :, b])
+
+
 def test_csm_graph_replay_gives_the_same_codes():
     """kk_csm_set_graph_mode: eager, captured and replayed single-token frames produce the codes of the eager run."""
     from mlx_audio_amd.csm import SesameModel

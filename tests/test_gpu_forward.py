@@ -267,13 +267,14 @@ def test_graph_replay_equals_eager_bitexact(dtype):
     eng.set_graph_mode(False)
 
 
-@pytest.mark.parametrize("dtype,flags", [("float32", 0), ("bfloat16", 0), ("bfloat16", 2), ("bfloat16", 1)])
-def test_result_does_not_depend_on_workspace_contents(dtype, flags):
+@pytest.mark.parametrize("dtype,flags,size", [("float32", 0, "tiny"), ("bfloat16", 0, "tiny"), ("bfloat16", 2, "tiny"), ("bfloat16", 1, "tiny"),
+                                              ("bfloat16", 0, "full"), ("bfloat16", 4, "full")])
+def test_result_does_not_depend_on_workspace_contents(dtype, flags, size):
     """Every byte the forward reads it has written first (or it is masked): a workspace full of 0xFF (NaN patterns in
     fp32 and bf16) gives the same bits as a zeroed one.  Guards the pad channels / pad rows of the MFMA path."""
     from mlx_audio_amd import _lib
 
-    cfg = P.tiny_config()
+    cfg = P.tiny_config() if size == "tiny" else P.kokoro_config()
     w = P.synth_checkpoint(cfg, 0)
     rng = np.random.default_rng(32)
     utts = [rng.integers(1, 178, n).tolist() for n in (12, 7, 9)]
