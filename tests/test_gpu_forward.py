@@ -337,6 +337,36 @@ def test_full_config_batch_invariance_bitexact(dtype):
     eng.set_graph_mode(False)
 
 
+@pytest.mark.parametrize("dtype,size", [("float32", "tiny"), ("bfloat16", "tiny"), ("bfloat16", "full")])
+def test_result_does_not_depend_on_the_frame_bound(dtype, size):
+    """Fmax only sizes buffers: a larger bound (more all-zero rows / tiles behind every utterance) leaves every produced sample unchanged,
+    and two identical calls give identical bits (no atomics anywhere on the path)."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.tiny_config() if size == "tiny" else P.kokoro_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(60)
+    utts = [rng.integers(1, 178, n).tolist() for n in (17, 6)]
+    eng = _engine(cfg, w, dtype)
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 2), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(2, device=dev)
+    forced = torch.full((2, Tmax), 4, dtype=torch.int32, device=dev)
+    need = 4 * Tmax
+    base = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, need, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=9)]
+    again = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, need, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=9)]
+    torch.cuda.synchronize()
+    assert torch.equal(base[0], again[0])
+    for extra in (1, 37, 200):
+        wav, pred, nfr = eng.forward(ids, lens, ref_s, sp, need + extra, forced_dur=forced, noise_mode=_lib.NOISE_ZERO)
+        wz, _, _ = eng.forward(ids, lens, ref_s, sp, need, forced_dur=forced, noise_mode=_lib.NOISE_ZERO)
+        torch.cuda.synchronize()
+        assert torch.equal(nfr, base[2])
+        assert torch.equal(wav[:, : 600 * need], wz), (dtype, size, extra)
+        assert bool((wav[:, 600 * need:] == 0).all())
+
+
 def test_text_audio_split_equals_fused():
     from mlx_audio_amd import _lib
 

@@ -90,6 +90,8 @@ def test_mimi_bf16_mode_tracks_the_fp32_oracle(which):
     e = err_stats(got, ref)
     report(f"mimi_bf16/{which}/pcm", **e)
     assert e["rms_rel"] < 3e-2 and e["rel_max"] < 6e-2, e
+    one = model.decode(torch.tensor(codes[1:2])).cpu().numpy()  # batch items are independent in bf16 mode too
+    np.testing.assert_array_equal(one[0], got[1])
 
 
 def test_mimi_reference_shape_known_answer_on_gpu():
