@@ -218,3 +218,23 @@ def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
     e = err_stats(res.audio.cpu().numpy(), ref_pcm)
     report("csm/e2e_tiny/pcm", **e)
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+
+
+def test_csm_golden_fixture_without_oracle():
+    """tests/golden/csm_tiny_case.npz (made by tests/golden/make_golden_codec.py): prompt block + 3 greedy frames, logits and codes."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "csm_tiny_case.npz"))
+    cfg = P.csm_tiny_config()
+    model = SesameModel_(cfg, P.csm_synth_checkpoint(cfg, int(g["weights_seed"])))
+    B, n = g["tokens"].shape[0], cfg["audio_num_codebooks"]
+    model.setup_caches(B)
+    t_in, m_in = g["tokens"], g["tokens_mask"]
+    for f in range(g["frames"].shape[0]):
+        c = model.generate_frame(torch.tensor(t_in), torch.tensor(m_in)).cpu().numpy()
+        e = err_stats(model.debug_logits().cpu().numpy(), g["logits"][f])
+        report(f"csm/golden/frame{f}/logits", **e)
+        assert e["rel_max"] < 2e-4, (f, e)
+        np.testing.assert_array_equal(c, g["frames"][f])
+        t_in = np.zeros((B, 1, n + 1), np.int32)
+        t_in[:, 0, :n] = c
+        m_in = np.zeros((B, 1, n + 1), np.float32)
+        m_in[:, 0, :n] = 1

@@ -149,3 +149,18 @@ def test_mimi_encode_matches_oracle(which):
     # decode(encode(x)) has the length of whole frames
     out = model.decode(codes)
     assert tuple(out.shape) == (B, 1, 1920 * Nf)
+
+
+def test_mimi_golden_fixture_without_oracle():
+    """tests/golden/mimi_tiny_case.npz (made by tests/golden/make_golden_codec.py): committed inputs and expected outputs; no oracle code runs."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mimi_tiny_case.npz"))
+    cfg = P.mimi_tiny_config()
+    model = Mimi(MimiConfig.from_dict(cfg), P.mimi_synth_checkpoint(cfg, int(g["weights_seed"]), encode=True))
+    pcm = model.decode(torch.tensor(g["codes"])).cpu().numpy()
+    e = err_stats(pcm, g["pcm_out"])
+    report("mimi/golden/pcm", **e)
+    assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+    codes = model.encode(torch.tensor(g["pcm_in"])).cpu().numpy()
+    assert (codes == g["codes_out"]).mean() > 0.97  # identical up to near-tie flips of the argmin
