@@ -106,16 +106,31 @@ def main():
     speed = torch.ones(B, device=dev)
     forced = torch.full((B, Tmax), FRAMES_PER_TOKEN, dtype=torch.int32, device=dev)
     Fmax = FRAMES_PER_TOKEN * Tmax
-    wav = torch.empty((B, 600 * Fmax), dtype=torch.float32, device=dev)
-    gathered = torch.empty((Bglob, 600 * Fmax), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    # two waveform buffers: with N > 1 the gather of batch i (the path's one exchange step: every shard's waveforms land on rank 0)
+    # runs on RCCL's stream while batch i+1 is synthesised into the other buffer
+    nbuf = 2 if world > 1 else 1
+    wavs = [torch.empty((B, 600 * Fmax), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    gathered = [torch.empty((Bglob, 600 * Fmax), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None for _ in range(nbuf)]
+    pending = [None] * nbuf
     eng.workspace(B, Tmax, Fmax)
 
     def step(i):
-        eng.forward(ids, lens, ref_s, speed, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=1000 + i, out=wav)
+        j = i % nbuf
+        if pending[j] is not None:
+            pending[j].wait()  # batch i-2 has left this buffer
+            pending[j] = None
+        eng.forward(ids, lens, ref_s, speed, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=1000 + i, out=wavs[j])
         if world > 1:
-            gather_waveforms(wav, gathered, dist)  # one exchange step: every shard's waveforms land on rank 0
+            pending[j] = gather_waveforms(wavs[j], gathered[j], dist, async_op=True)
+
+    def drain():
+        for j in range(nbuf):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     def barrier():
+        drain()  # every exchange of the region has completed before the clock is read
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -126,7 +141,7 @@ def main():
     use_graph = not args.no_graph
     if use_graph:
         eng.set_graph_mode(True)
-    nwarm = max(args.warmup, 2) if use_graph else args.warmup
+    nwarm = max(args.warmup, 2 * nbuf) if use_graph else args.warmup  # eager run + capture per output buffer happen before the clock starts
     for i in range(nwarm):
         step(i)
     barrier()

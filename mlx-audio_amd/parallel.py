@@ -28,16 +28,17 @@ def balanced_assignment(costs: Sequence[float], world: int) -> List[List[int]]:
     return out
 
 
-def gather_waveforms(local: torch.Tensor, out_root: Optional[torch.Tensor], dist, dst: int = 0) -> None:
+def gather_waveforms(local: torch.Tensor, out_root: Optional[torch.Tensor], dist, dst: int = 0, async_op: bool = False):
     """Equal-shape gather: rank r's [B, N] block lands in out_root[r*B:(r+1)*B] on `dst`.  With RCCL this is one
-    grouped send/recv: every peer writes to the root over its own xGMI link (no ring)."""
+    grouped send/recv: every peer writes to the root over its own xGMI link (no ring).  async_op=True returns the work handle:
+    the exchange then runs on the collective's own stream while the next batch is being synthesised (the caller must keep `local`
+    and `out_root` untouched until handle.wait())."""
     world = dist.get_world_size()
     if dist.get_rank() == dst:
         B = local.shape[0]
         chunks = [out_root[r * B : (r + 1) * B] for r in range(world)]
-        dist.gather(local, gather_list=chunks, dst=dst)
-    else:
-        dist.gather(local, gather_list=None, dst=dst)
+        return dist.gather(local, gather_list=chunks, dst=dst, async_op=async_op)
+    return dist.gather(local, gather_list=None, dst=dst, async_op=async_op)
 
 
 def gather_ragged(local: torch.Tensor, nsamples: torch.Tensor, dist, dst: int = 0):

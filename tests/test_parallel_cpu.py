@@ -52,6 +52,16 @@ def _worker(rank, world, port, q):
         if rank == 0:
             for r in range(world):
                 ok &= bool(torch.equal(out[r * B : (r + 1) * B], torch.arange(B * N, dtype=torch.float32).reshape(B, N) + 1000 * r))
+        # asynchronous form, two batches in flight on alternating buffers (what bench.py does to hide the exchange)
+        outs = [torch.zeros((world * B, N)) if rank == 0 else None for _ in range(2)]
+        locs = [local + 7.0 * j for j in range(2)]
+        hs = [par.gather_waveforms(locs[j], outs[j], dist, async_op=True) for j in range(2)]
+        for h in hs:
+            h.wait()
+        if rank == 0:
+            for j in range(2):
+                for r in range(world):
+                    ok &= bool(torch.equal(outs[j][r * B : (r + 1) * B], torch.arange(B * N, dtype=torch.float32).reshape(B, N) + 1000 * r + 7.0 * j))
         # ragged
         ns = torch.tensor([10 + rank, 50, 3 * (rank + 1)], dtype=torch.int32)
         rag = par.gather_ragged(local, ns, dist)
