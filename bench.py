@@ -34,6 +34,7 @@ SR = 24000
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense; never the 2:1 sparse marketing numbers)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 PEAK_HBM_GBS = 8000.0
+PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled fp8 (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(cfg, w, utt, ref_s):
@@ -63,6 +64,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 p50 latency measurement")
+    ap.add_argument("--quantized", action="store_true",
+                    help="BASELINE config 5: the checkpoint goes through the MLX 8-bit group quantisation (group 64) of the reference's predicate and "
+                         "its linears run on the fp8 matrix instruction; use with --batch 64.  The default run is config 2 (the headline).")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
     args = ap.parse_args()
 
@@ -87,9 +91,19 @@ def main():
 
     cfg = P.kokoro_config()
     w = P.synth_checkpoint(cfg, 0)
-    if args.dtype == "bfloat16":
+    quantization = None
+    if args.quantized:
+        if args.dtype != "bfloat16":
+            raise SystemExit("--quantized is the bf16 + fp8 configuration")
+        from mlx_audio_amd.quant import dequantize_checkpoint, quantize_checkpoint
+
+        quantization = {"group_size": 64, "bits": 8}
+        w = dequantize_checkpoint(quantize_checkpoint(w, 64, 8), 64, 8)  # what load_model hands the engine for an 8-bit checkpoint
+    if args.dtype == "bfloat16" and not args.quantized:
         w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
-    eng = KokoroEngine(cfg, w, compute_dtype=args.dtype)
+    eng = KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization)
+    if args.quantized:
+        assert eng.lib.kk_quantized_layers(eng._h) == 6
     dev = eng.device
 
     # ---- synthetic workload: global batch = world * B utterances, this rank takes its contiguous shard
@@ -181,9 +195,9 @@ def main():
         dt = float(t.item())
 
     audio_s = Bglob * (600 * Fmax) / SR * args.steps
-    dtype_tag = "bf16" if args.dtype == "bfloat16" else "f32"
+    dtype_tag = ("bf16+fp8(e4m3, quantised linears)" if args.quantized else "bf16") if args.dtype == "bfloat16" else "f32"
     out = {
-        "metric": "audio-sec/sec (xRT), Kokoro-82M batch=32 fixed 128-phoneme utterances per GPU",
+        "metric": f"audio-sec/sec (xRT), Kokoro-82M{' 8-bit quantised' if args.quantized else ''} batch={B} fixed 128-phoneme utterances per GPU",
         "value": audio_s / dt,
         "unit": "audio-sec/sec",
         "n_gpus": world,
@@ -217,6 +231,11 @@ def main():
             if pmc and conv is prof["conv_mfma"] and "conv_mfma" in pmc:
                 c = pmc["conv_mfma"]  # separate --pmc passes, see profiles/r01_pmc_traffic.json (read side reported raw)
                 traffic = (c["fetch_raw_bytes_per_step"] + c["write_bytes_per_step"]) / c["launches_per_step"]
+            if prof.get("linear_mxfp8", {}).get("ms", 0) > 0:
+                q = prof["linear_mxfp8"]  # activation pre-pass + block-scaled fp8 product, bracketed together
+                qa = q["flops"] / (q["ms"] * 1e-3) / 1e12
+                out["roofline_linear_mxfp8"] = {"bound": "mfma", "achieved": qa, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": qa / PEAK_FP8_TFLOPS,
+                                                "launches_per_step": q["launches"] / args.steps, "ms_per_step": q["ms"] / args.steps}
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma" if conv is prof["conv_mfma"] else "conv_generic (fp32 VALU implicit GEMM)",
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "launches_per_step": conv["launches"] / args.steps, "ms_per_step": conv["ms"] / args.steps}

@@ -107,6 +107,17 @@ int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, c
  * kokoro.py:120-170 is re-traced every time). */
 int kk_set_graph_mode(kk_model* m, int on);
 
+/* load_model's quantization branch  --  mlx_audio/tts/utils.py:241-260 (nn.quantize with the class predicate of :349-369; BASELINE
+ * config 5).  Call between kk_create and kk_finalize when config["quantization"] is present; the weights handed to kk_load_tensor are
+ * the DEQUANTISED ones (scale * q + bias per group, mlx-audio_amd/quant.py).  With compute_dtype bf16 the quantised Linear set with
+ * eligible shapes (inputs % 64 == 0, outputs % 64 == 0: Albert's embedding map / QKV / dense / ffn / ffn_output and bert_encoder,
+ * 99.9 % of the quantised FLOPs) is re-quantised to OCP e4m3 with one power-of-two (E8M0) scale per `group_size` inputs and runs on
+ * the block-scaled fp8 matrix instruction; activations are quantised per (row, 32 inputs) on the fly.  The remaining members of the
+ * set (style `fc` layers, duration_proj, embeddings: M = batch rows or table lookups) use the dequantised weights in fp32.
+ * bits must be 8.  kk_quantized_layers reports how many of the 6 linears got an fp8 pack (after kk_finalize). */
+int kk_set_quantization(kk_model* m, int group_size, int bits);
+int kk_quantized_layers(const kk_model* m);
+
 const char* kk_last_error(void);
 int kk_abi_version(void);
 
@@ -153,6 +164,16 @@ int kk_op_source_stft(void* stream, int B, const float* f0, int L2_rows, const i
 /* exp/sin + MLXSTFT.inverse + istft  --  istftnet.py:804-806,497-523; mlx_audio/utils.py:104-158 */
 int kk_op_istft_head(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, float* wav, int dtype, int fast);
 
+/* MX-fp8 linear  --  the quantised nn.Linear of the reference's 8-bit checkpoints (mx.quantized_matmul, tts/utils.py:255-260).
+ * kk_mxfp8_pack_weight (HOST to HOST): fp32 [N][K] -> e4m3 fragments + E8M0 scale bytes in MFMA fragment order, buffer sizes from
+ * kk_mxfp8_bytes(N, K, ..).  kk_op_linear_mxfp8: x bf16 [M][ldx] (M = items * rows_per_item; len[item] valid rows, NULL = all) is
+ * quantised into the caller's aq / as scratch (sizes kk_mxfp8_bytes(M, K, ..)), then out[m][n] = act(sum_k x[m][k] w[n][k] + bias[n])
+ * in bf16, zero for rows past len.  act: 0 none, 2 exact GELU. */
+int kk_mxfp8_bytes(int rows, int K, size_t* q_bytes, size_t* s_bytes);
+int kk_mxfp8_pack_weight(const float* w_host, int N, int K, int group, uint8_t* q_host, uint8_t* s_host);
+int kk_op_linear_mxfp8(void* stream, const void* x_bf16, int ldx, int M, int rows_per_item, const int32_t* len, int K, const void* wq,
+                       const void* ws, int N, const float* bias, int act, void* aq, void* as, void* out_bf16, int ldo);
+
 /* ---- debug hooks (tests only; not thread safe) ----
  * Named intermediates of the last kk_forward*: "bert_dur" "d" "t_en" "en" "asr" "F0_pred" "N_pred" "dec_out"
  * "har_source" "har" "gen_pre_res0" "gen_stage0" "gen_pre_res1" "gen_stage1" "conv_post".
@@ -166,11 +187,11 @@ void kk_debug_clear(kk_model* m);
  * with that pack (NULL = back to the LDS-staged kernel).  The model packs both layouts in kk_finalize. */
 int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP);
 void kk_debug_set_op_wfrag(const void* w_frag);
-void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4 */
+void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4, bit3 quantised model without the fp8 kernel */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention
- *          8 source 9 stft.  kk_profile_end returns summed milliseconds, algorithmic flops / bytes and launch counts. */
+ *          8 source 9 stft 10 linear_mxfp8.  kk_profile_end returns summed milliseconds, algorithmic flops / bytes and launch counts. */
 int kk_profile_begin(kk_model* m, int max_launches);
 int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count);
 

@@ -102,6 +102,11 @@ SIGNATURES = {
     "kk_mimi_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_set_op_wfrag": (None, [_vp]),
     "kk_set_graph_mode": (_i, [_vp, _i]),
+    "kk_set_quantization": (_i, [_vp, _i, _i]),
+    "kk_quantized_layers": (_i, [_vp]),
+    "kk_mxfp8_bytes": (_i, [_i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "kk_mxfp8_pack_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "kk_op_linear_mxfp8": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
     "kk_profile_begin": (_i, [_vp, _i]),
     "kk_profile_end": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -223,3 +223,25 @@ int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_f
 int kk_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st);  // one 8-byte device store (graph-replay seed)
 int kk_launch_convert(const void* src, int sdt, long long sbs, int lds, void* dst, int ddt, long long dbs, int ldd, int C, int rows, int B,
                       hipStream_t st);
+
+// ---- MX-fp8 linears (kk_mxfp8.hip).  Operands in MFMA fragment order, see the header of kk_mxfp8.hip.
+struct KKFp8Args {
+  const uint4* aq;          // activation fragments (kk_launch_mxfp8_quant_rows)
+  const unsigned char* as;  // activation scale bytes
+  const uint4* wq;          // weight fragments (kk_mxfp8_pack_weight_host, uploaded)
+  const unsigned char* ws;
+  int M, N, K;              // flat rows, outputs (N % 64 == 0), inputs (K % 64 == 0)
+  const float* bias;        // [N] or null
+  bf16_t* out;              // out[m * ldo + n]
+  int ldo;
+  int rows_per_item;        // row m belongs to utterance m / rows_per_item at position m % rows_per_item
+  KKLen lout;               // rows at positions past the utterance's length are written as zeros
+  int act;                  // KK_ACT_NONE or KK_ACT_GELU (exact erf)
+};
+size_t kk_mxfp8_q_bytes(int rows, int K);
+size_t kk_mxfp8_s_bytes(int rows, int K);
+bool kk_mxfp8_eligible(int K, int N);
+// host: fp32 [N][K] -> e4m3 fragments + E8M0 scale bytes, one scale per `group` inputs (a multiple of 32)
+int kk_mxfp8_pack_weight_host(const float* w, int N, int K, int group, unsigned char* q, unsigned char* s);
+int kk_launch_mxfp8_quant_rows(const void* x_bf16, int ldx, int M, int K, void* aq, void* as, hipStream_t st);
+int kk_launch_linear_mxfp8(const KKFp8Args& a, hipStream_t st);

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <string>
@@ -60,6 +61,11 @@ struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
   int CinP = 0, CoutP = 0, Cout8 = 0;
   const bf16_t* wb = nullptr;
   const bf16_t* wf = nullptr;  // the same weights in MFMA fragment order (variant-4 kernel, kk_mfma4_pack_index)
+  // MX-fp8 pack (kk_set_quantization, bf16 mode, the reference's quantised layer set only): e4m3 fragments + E8M0 scale bytes
+  bool fp8 = false;
+  size_t q8_off = 0, s8_off = 0;
+  const uint4* q8 = nullptr;
+  const unsigned char* s8 = nullptr;
 };
 struct VecW {
   size_t off = 0;
@@ -161,6 +167,8 @@ struct kk_model {
   unsigned long long* seed_dev = nullptr;  // the Philox seed of a replayed forward
   bool capturing = false;
   bool no_v4 = false;
+  bool no_fp8 = false;  // tests: quantised model, but the Q1 layer set runs on the bf16 kernel with the same (dequantised) weights
+  int q_group = 0;      // kk_set_quantization: group size of the MLX affine quantisation the checkpoint went through (0 = none)
   hipStream_t cap_stream = nullptr;
   struct ProfRec { int cls; double flops; double bytes; };
   std::vector<ProfRec> prof_rec;
@@ -367,6 +375,16 @@ struct Packer {
           dfr[kk_mfma4_pack_index(k, o, i, c.CoutP, c.CinP)] = v;
         }
   }
+  // MX-fp8 pack of a Linear weight wsrc[o][i] (the layer set of the reference's quantisation predicate, tts/utils.py:241-260):
+  // e4m3 with one power-of-two scale per `q_group` inputs, in MFMA fragment order (kk_mxfp8.hip)
+  void pack_fp8(ConvW& c, const std::vector<float>& wsrc, int O, int I) {
+    if (!m->q_group || m->adt != KK_BF16 || !kk_mxfp8_eligible(I, O) || I % m->q_group) return;
+    const size_t qb = kk_mxfp8_q_bytes(O, I), sb = kk_mxfp8_s_bytes(O, I);
+    c.q8_off = alloc((qb + 3) / 4);
+    c.s8_off = alloc((sb + 3) / 4);
+    if (kk_mxfp8_pack_weight_host(wsrc.data(), O, I, m->q_group, (unsigned char*)&m->pack[c.q8_off], (unsigned char*)&m->pack[c.s8_off]) == 0)
+      c.fp8 = true;
+  }
   // pack a conv weight given as wsrc[o][k][i] into [k][i][ldw]
   ConvW pack_oki(const std::vector<float>& wsrc, int O, int K, int I, const std::vector<float>* bias) {
     ConvW c;
@@ -452,11 +470,13 @@ struct Packer {
     return c;
   }
   // nn.Linear: weight [O][I], bias [O]
-  ConvW linear(const std::string& prefix, int O, int I) {
+  ConvW linear(const std::string& prefix, int O, int I, bool quantised = false) {
     std::vector<float> w, b;
     if (!vec(prefix + ".weight", (size_t)O * I, w)) return ConvW();
     if (!vec(prefix + ".bias", (size_t)O, b)) return ConvW();
-    return pack_oki(w, O, 1, I, &b);
+    ConvW c = pack_oki(w, O, 1, I, &b);
+    if (quantised) pack_fp8(c, w, O, I);
+    return c;
   }
   LstmW lstm(const std::string& prefix, int I, int H) {
     LstmW l;
@@ -562,6 +582,8 @@ void resolve(kk_model* m, ConvW& c) {
   c.b = c.has_bias ? m->dev + c.b_off : nullptr;
   c.wb = c.mfma ? (const bf16_t*)(m->dev + c.wb_off) : nullptr;
   c.wf = c.mfma ? (const bf16_t*)(m->dev + c.wf_off) : nullptr;
+  c.q8 = c.fp8 ? (const uint4*)(m->dev + c.q8_off) : nullptr;
+  c.s8 = c.fp8 ? (const unsigned char*)(m->dev + c.s8_off) : nullptr;
 }
 void resolve(kk_model* m, VecW& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_model* m, LstmW& l) {
@@ -595,7 +617,7 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   m->emb_type = P.put_named("bert.embeddings.token_type_embeddings.weight", (size_t)2 * E);
   m->emb_ln_w = P.put_named("bert.embeddings.LayerNorm.weight", E);
   m->emb_ln_b = P.put_named("bert.embeddings.LayerNorm.bias", E);
-  m->map_in = P.linear("bert.encoder.embedding_hidden_mapping_in", hs, E);
+  m->map_in = P.linear("bert.encoder.embedding_hidden_mapping_in", hs, E, true);
   const std::string lp = "bert.encoder.albert_layer_groups.0.albert_layers.0.";
   {
     std::vector<float> w((size_t)3 * hs * hs), b((size_t)3 * hs);
@@ -608,15 +630,16 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
       }
     }
     m->qkv = P.pack_oki(w, 3 * hs, 1, hs, &b);
+    P.pack_fp8(m->qkv, w, 3 * hs, hs);
   }
-  m->att_dense = P.linear(lp + "attention.dense", hs, hs);
+  m->att_dense = P.linear(lp + "attention.dense", hs, hs, true);
   m->att_ln_w = P.put_named(lp + "attention.LayerNorm.weight", hs);
   m->att_ln_b = P.put_named(lp + "attention.LayerNorm.bias", hs);
   m->full_ln_w = P.put_named(lp + "full_layer_layer_norm.weight", hs);
   m->full_ln_b = P.put_named(lp + "full_layer_layer_norm.bias", hs);
-  m->ffn = P.linear(lp + "ffn", c.plbert_intermediate, hs);
-  m->ffn_out = P.linear(lp + "ffn_output", hs, c.plbert_intermediate);
-  m->bert_encoder = P.linear("bert_encoder", H, hs);
+  m->ffn = P.linear(lp + "ffn", c.plbert_intermediate, hs, true);
+  m->ffn_out = P.linear(lp + "ffn_output", hs, c.plbert_intermediate, true);
+  m->bert_encoder = P.linear("bert_encoder", H, hs, true);
   // ---- prosody predictor (modules.py:288-342,380-387)
   for (int i = 0; i < c.n_layer; ++i) {
     m->dur_lstms.push_back(P.lstm("predictor.text_encoder.lstms." + std::to_string(2 * i), H + S, H / 2));
@@ -835,6 +858,19 @@ struct Ctx {
     const double flops = 2.0 * B * rows_out * w.Cout * (o.alg_taps_cin > 0 ? o.alg_taps_cin : w.Cin * taps);
     const double bytes = B * (rows_out * w.Cout * esz(out.dtype) * (o.res ? 2.0 : 1.0) + (double)Q * (o.mode == KK_CONVT ? 1 : o.stride) * w.Cin * esz(x.dtype)) +
                          (double)w.Kw * w.Cin * w.Cout * 4.0;
+    if (can_fp8(w, x, lin, out, lout, Q, o)) {
+      // the reference's quantised layer set (tts/utils.py:241-260) on the block-scaled fp8 matrix instruction: activation pre-pass, then the product
+      KKFp8Args f;
+      memset(&f, 0, sizeof f);
+      f.aq = (const uint4*)q8_aq; f.as = (const unsigned char*)q8_as; f.wq = w.q8; f.ws = w.s8;
+      f.M = B * x.rows; f.N = w.Cout; f.K = w.Cin; f.bias = w.b; f.out = (bf16_t*)out.p; f.ldo = out.ld; f.rows_per_item = x.rows;
+      f.lout = lout; f.act = o.act;
+      prof_start();
+      int rc = kk_launch_mxfp8_quant_rows(x.p, x.ld, f.M, f.K, q8_aq, q8_as, st);
+      if (rc == 0) rc = kk_launch_linear_mxfp8(f, st);
+      prof_stop(10, flops, B * (double)Q * (w.Cin * 2.0 + w.Cin * 1.03 * 2.0 + w.Cout * 2.0) + (double)w.Cin * w.Cout * 1.03);
+      return rc;
+    }
     if (can_mfma(w, x, out, o)) {
       KKMfmaArgs g;
       memset(&g, 0, sizeof g);
@@ -865,6 +901,18 @@ struct Ctx {
     const int rc = kk_launch_conv_generic(a, B, x.dtype, out.dtype, st);
     prof_stop(0, flops, bytes);
     return rc;
+  }
+
+  // MX-fp8 linear: a plain Linear (k = 1, bias, optional exact GELU) between two whole bf16 buffers of the same row count
+  void* q8_aq = nullptr;  // activation fragments / scale bytes of the launch in flight (run_text allocates them)
+  void* q8_as = nullptr;
+  size_t q8_rows = 0, q8_K = 0;
+  bool can_fp8(const ConvW& w, const Buf& x, KKLen lin, const Buf& out, KKLen lout, int Q, const ConvOpt& o) const {
+    return w.fp8 && !m->no_fp8 && !m->force_generic && q8_aq && x.dtype == KK_BF16 && out.dtype == KK_BF16 && w.Kw == 1 && o.mode == KK_CONV &&
+           o.stride == 1 && o.pad == 0 && o.dil == 1 && o.in_shift == 0 && o.in_slope == 1.f && !o.res && o.scale == 1.f && !o.accumulate &&
+           (o.act == KK_ACT_NONE || o.act == KK_ACT_GELU) && !o.nrm_a && !o.want_stats && x.rows == out.rows && Q == x.rows &&
+           x.bs == (long long)x.rows * x.ld && out.bs == (long long)out.rows * out.ld && x.ld % 8 == 0 && !((uintptr_t)x.p & 15) &&
+           lin.len == lout.len && lin.mul == lout.mul && lin.add == lout.add && (size_t)B * x.rows <= q8_rows && (size_t)w.Cin <= q8_K;
   }
 
   bool can_mfma(const ConvW& w, const Buf& x, const Buf& out, const ConvOpt& o) const {
@@ -917,17 +965,17 @@ struct Ctx {
   // rows one workgroup of the stand-alone statistics pass walks: short tensors (decoder, F rows) need more workgroups
   // a CONSTANT: the grouping of the partial sums must not depend on the longest utterance of the batch, or an utterance's statistics (and
   // every sample after them) change in the last bit with its neighbours (found by test_full_config_batch_invariance_bitexact)
-  static int rows_per_chunk(int Lmax) {
-    (void)Lmax;
-    return 256;
-  }
+  // -- so it is chosen by the tensor's length DOMAIN (rows per predicted frame: 1 / 2 for the decoder and F0 / N stacks, 20 / 120 for the
+  // generator stages), a static property of the layer: short tensors get 64-row chunks (enough workgroups), long ones 512
+  static int rows_per_chunk(int rows_per_frame) { return rows_per_frame >= 20 ? 512 : 64; }
+  int Fcap = 0;  // frame capacity of this call (run_audio): Lmax / Fcap = the tensor's rows per frame
 
   int stats(const Buf& x, int C, int Lmax, KKLen len) {
     if (dry) return 0;
     KKStatsArgs a;
     memset(&a, 0, sizeof a);
     a.x = x.p; a.xbs = x.bs; a.ldx = x.ld; a.C = C; a.Lmax = Lmax; a.len = len;
-    a.partial = st_partial; a.rows_per_chunk = rows_per_chunk(Lmax); a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
+    a.partial = st_partial; a.rows_per_chunk = rows_per_chunk(Fcap > 0 ? Lmax / Fcap : 1); a.mean = st_mean; a.rstd = st_rstd; a.eps = 1e-5f;
     prof_start();
     const int rc = kk_launch_instnorm_stats(a, B, x.dtype, st);
     prof_stop(2, 3.0 * B * Lmax * C, (double)B * Lmax * C * esz(x.dtype));
@@ -1121,6 +1169,13 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
   const kk_config& cf = m->cfg;
   const int H = cf.hidden_dim, hs = cf.plbert_hidden, E = cf.plbert_embedding, B = c.B;
   const KKLen lT{lens, 1, 0};
+  if (m->q_group && m->adt == KK_BF16) {  // MX-fp8 activation scratch of the quantised linears (largest K of the layer set)
+    c.q8_rows = (size_t)B * Tmax;
+    c.q8_K = (size_t)std::max(std::max(hs, E), (int)cf.plbert_intermediate);
+    c.q8_aq = c.raw(kk_mxfp8_q_bytes((int)c.q8_rows, (int)c.q8_K));
+    c.q8_as = c.raw(kk_mxfp8_s_bytes((int)c.q8_rows, (int)c.q8_K));
+    if (c.dry) c.q8_aq = nullptr;
+  }
   // ---- Albert
   Buf e = c.act(Tmax, E), x = c.act(Tmax, hs), qkv = c.act(Tmax, 3 * hs), ctxb = c.act(Tmax, hs), att = c.act(Tmax, hs),
       ff = c.act(Tmax, cf.plbert_intermediate), tmp = c.act(Tmax, hs);
@@ -1207,6 +1262,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   const int u0 = cf.upsample_rates[0], u1 = cf.upsample_rates[1], hop = cf.gen_istft_hop_size;
   const int L2 = 2 * Fmax, L20 = L2 * u0, Tf = L20 * u1 + 1, Nw = L20 * u1 * hop;
   const int C0 = cf.upsample_initial_channel, nk = cf.n_resblock_kernels;
+  c.Fcap = Fmax;
   // ---- alignment + length regulation (kokoro.py:151-157,162)
   int* frame_idx = c.i32((size_t)B * Fmax);
   int* lenF = c.i32(B);
@@ -1241,7 +1297,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     // upper bounds: partial = B * chunks(L) * 2 * C for every (L, C) pair used below
     size_t pmax = 0, cmax = 0;
     auto upd = [&](int L, int C) {
-      pmax = std::max(pmax, kk_stats_partial_floats(B, C, L, Ctx::rows_per_chunk(L)));
+      pmax = std::max(pmax, kk_stats_partial_floats(B, C, L, 64));  // the smallest chunk any domain uses
       cmax = std::max(cmax, (size_t)B * C);
     };
     upd(Fmax, H); upd(L2, H); upd(L2, H / 2); upd(Fmax, H + 2); upd(Fmax, DH + 2 + 64); upd(Fmax, DH); upd(L2, DH + 2 + 64);
@@ -1724,6 +1780,53 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
   m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
   m->no_v4 = (on & 4) != 0;          // bit 2: the LDS-staged MFMA kernel (variant 2) instead of variant 4
+  m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
+}
+
+// load_model's quantization branch (mlx_audio/tts/utils.py:241-260): the checkpoint's Linear / Embedding weights went through MLX's
+// affine `bits`-bit group quantisation.  The caller hands over the DEQUANTISED weights (quant.py); with compute_dtype bf16 the
+// layer set with eligible shapes (Albert's five linears, bert_encoder) is re-quantised in kk_finalize to e4m3 with one
+// power-of-two scale per group and runs on v_mfma_scale_f32_32x32x64_f8f6f4.
+extern "C" int kk_set_quantization(kk_model* m, int group_size, int bits) {
+  if (!m) return kk_fail("kk_set_quantization: null model");
+  if (m->finalized) return kk_fail("kk_set_quantization: call before kk_finalize");
+  if (bits != 8) return kk_fail("kk_set_quantization: only the 8-bit path exists (bits must be 8)");
+  if (group_size < 32 || group_size % 32) return kk_fail("kk_set_quantization: group_size must be a multiple of 32");
+  if (m->adt != KK_BF16) return kk_fail("kk_set_quantization: the fp8 path needs compute_dtype bf16");
+  m->q_group = group_size;
+  return 0;
+}
+extern "C" int kk_quantized_layers(const kk_model* m) {
+  if (!m || !m->finalized) return -1;
+  const ConvW* set[] = {&m->map_in, &m->qkv, &m->att_dense, &m->ffn, &m->ffn_out, &m->bert_encoder};
+  int n = 0;
+  for (const ConvW* c : set) n += c->fp8 ? 1 : 0;
+  return n;
+}
+
+// ---- MX-fp8 single-op entry points (tests)
+extern "C" int kk_mxfp8_bytes(int rows, int K, size_t* q_bytes, size_t* s_bytes) {
+  if (rows <= 0 || K <= 0 || K % 64 || !q_bytes || !s_bytes) return kk_fail("kk_mxfp8_bytes: bad argument");
+  *q_bytes = kk_mxfp8_q_bytes(rows, K);
+  *s_bytes = kk_mxfp8_s_bytes(rows, K);
+  return 0;
+}
+extern "C" int kk_mxfp8_pack_weight(const float* w_host, int N, int K, int group, uint8_t* q_host, uint8_t* s_host) {
+  if (!w_host || !q_host || !s_host) return kk_fail("kk_mxfp8_pack_weight: null argument");
+  return kk_mxfp8_pack_weight_host(w_host, N, K, group, q_host, s_host);
+}
+extern "C" int kk_op_linear_mxfp8(void* stream, const void* x_bf16, int ldx, int M, int rows_per_item, const int32_t* len, int K,
+                                  const void* wq, const void* ws, int N, const float* bias, int act, void* aq, void* as, void* out_bf16,
+                                  int ldo) {
+  if (!x_bf16 || !wq || !ws || !aq || !as || !out_bf16) return kk_fail("kk_op_linear_mxfp8: null argument");
+  KK_TRY(kk_launch_mxfp8_quant_rows(x_bf16, ldx, M, K, aq, as, (hipStream_t)stream));
+  KKFp8Args f;
+  memset(&f, 0, sizeof f);
+  f.aq = (const uint4*)aq; f.as = (const unsigned char*)as; f.wq = (const uint4*)wq; f.ws = (const unsigned char*)ws;
+  f.M = M; f.N = N; f.K = K; f.bias = bias; f.out = (bf16_t*)out_bf16; f.ldo = ldo; f.rows_per_item = rows_per_item;
+  f.lout = KKLen{len, len ? 1 : 0, len ? 0 : rows_per_item};
+  f.act = act;
+  return kk_launch_linear_mxfp8(f, (hipStream_t)stream);
 }
 extern "C" void kk_debug_set_op_wfrag(const void* w_frag) { g_op_wfrag = w_frag; }
 extern "C" int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP) {

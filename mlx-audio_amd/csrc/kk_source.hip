@@ -17,6 +17,8 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct Tables {
   float hann_sym[20];  // utils.py:10-14, forward STFT window
   float hann_per[20];  // hanning(21)[:-1], utils.py:121, inverse window
@@ -436,6 +438,140 @@ __global__ __launch_bounds__(256) void istft_head_wave_kernel(const T* x, long l
   }
 }
 
+
+// ------------------------------------------------------------------ iSTFT head, wave-local FAST form (bf16 mode)
+// The same lane-per-frame structure as istft_head_wave_kernel<T, true>, with everything that does not depend on the data folded
+// into literals: twiddles carry the factor 2 of the real inverse DFT (exact), the output scale is 0.5 * 0.05 * hann_per[o] -- the
+// interior window sum of a periodic Hann at hop N/4 is exactly 2.0f in float32 for every r in this summation order, so interior
+// samples need no division at all -- and invalid frames contribute exact zeros, so the overlap-add is four unconditional adds in
+// ascending frame order.  Only waves that touch an utterance edge (first 3 hop blocks, the block after the last frame) take the
+// branch that rebuilds the partial window sum.  472 -> ~330 VALU instructions per wave of 61 hop blocks; sin / cos of the phase's sine (|.| <= 1) are a
+// packed polynomial; what remains quarter-rate is exp and the first sin: 22 transcendentals per frame.
+template <typename T>
+__global__ __launch_bounds__(256) void istft_head_wave_fast_kernel(const T* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav,
+                                                                   long long wbs, Tables tb) {
+  constexpr float CS2[20] = {2.0f, 1.9021130800247192f, 1.6180340051651f, 1.1755704879760742f, 0.6180340051651001f, 0.0f, -0.6180340051651001f,
+                             -1.1755704879760742f, -1.6180340051651f, -1.9021130800247192f, -2.0f, -1.9021130800247192f, -1.6180340051651f,
+                             -1.1755704879760742f, -0.6180340051651001f, 0.0f, 0.6180340051651001f, 1.1755704879760742f, 1.6180340051651f,
+                             1.9021130800247192f};
+  constexpr float SN2[20] = {0.0f, 0.6180340051651001f, 1.1755704879760742f, 1.6180340051651f, 1.9021130800247192f, 2.0f, 1.9021130800247192f,
+                             1.6180340051651f, 1.1755704879760742f, 0.6180340051651001f, 0.0f, -0.6180340051651001f, -1.1755704879760742f,
+                             -1.6180340051651f, -1.9021130800247192f, -2.0f, -1.9021130800247192f, -1.6180340051651f, -1.1755704879760742f,
+                             -0.6180340051651001f};
+  // 0.5 * (0.05f * hann_per[o])
+  constexpr float KH[20] = {0.0f, 0.5f * 0.0012235870817676187f, 0.5f * 0.004774575587362051f, 0.5f * 0.010305369272828102f,
+                            0.5f * 0.01727457530796528f, 0.5f * 0.02500000037252903f, 0.5f * 0.03272542357444763f, 0.5f * 0.03969463333487511f,
+                            0.5f * 0.04522542282938957f, 0.5f * 0.04877641424536705f, 0.5f * 0.05000000074505806f, 0.5f * 0.04877641424536705f,
+                            0.5f * 0.04522542282938957f, 0.5f * 0.03969463333487511f, 0.5f * 0.03272542357444763f, 0.5f * 0.02500000037252903f,
+                            0.5f * 0.01727457530796528f, 0.5f * 0.010305369272828102f, 0.5f * 0.004774575587362051f, 0.5f * 0.0012235870817676187f};
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Tf = len_frames ? len_frames[b] : Tfmax;
+  const int g0 = (blockIdx.x * 4 + wv) * IW_HB;
+  if (g0 >= Tfmax + 3) return;
+  const int f = g0 - 3 + lane;
+  const bool fv = f >= 0 && f < Tf;
+  float y[20];
+#pragma unroll
+  for (int o = 0; o < 20; ++o) y[o] = 0.f;
+  if (fv) {
+    const T* xr = x + (long long)b * xbs + (long long)f * ldx;
+    float in[22];
+    if (sizeof(T) == 2 && (ldx & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)xbs * 2)) & 15) == 0) {
+      uint4 r[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) r[q] = *((const uint4*)xr + q);
+      const unsigned w[12] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w};
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        in[2 * k] = __uint_as_float(w[k] << 16);
+        in[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 22; ++k) in[k] = kk_ld(xr + k);
+    }
+    float re[11], im[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float mag = __expf(in[k]);
+      const float ph = __sinf(in[11 + k]);
+      // cos(ph), sin(ph) for |ph| <= 1: Taylor to ph^10 / ph^11 (truncation < 3e-9) as ONE packed Horner chain over the pair --
+      // five v_pk_fma_f32 instead of two quarter-rate v_sin / v_cos, and (re, im) come out as a register pair
+      const float t = ph * ph;
+      v2f acc = {-2.7557319223985888e-07f, -2.505210838544172e-08f};
+      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{2.48015873015873e-05f, 2.7557319223985893e-06f});
+      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{-1.3888888888888889e-03f, -1.984126984126984e-04f});
+      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{4.1666666666666664e-02f, 8.333333333333333e-03f});
+      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{-0.5f, -1.6666666666666666e-01f});
+      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{1.0f, 1.0f});
+      const v2f ri = acc * v2f{mag, mag * ph};
+      re[k] = ri.x;
+      im[k] = (k == 0 || k == 10) ? 0.f : ri.y;  // the inverse real FFT ignores the imaginary part of DC / Nyquist
+    }
+    const float dcp = re[0] + re[10], dcm = re[0] - re[10];
+#pragma unroll
+    for (int o = 0; o <= 5; ++o) {
+      float Ce = 0.f, Co = 0.f, Se = 0.f, So = 0.f;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) {
+        const int m = (k * o) % 20;
+        if (k & 1) {
+          Co = __builtin_fmaf(re[k], CS2[m], Co);
+          So = __builtin_fmaf(im[k], SN2[m], So);
+        } else {
+          Ce = __builtin_fmaf(re[k], CS2[m], Ce);
+          Se = __builtin_fmaf(im[k], SN2[m], Se);
+        }
+      }
+      {
+        const float C = Ce + Co, S = Se + So;
+        const float dc = (o & 1) ? dcm : dcp;
+        y[o] = (dc + (C - S)) * KH[o];
+        if (o > 0) y[20 - o] = (dc + (C + S)) * KH[20 - o];
+      }
+      if (o < 5) {
+        const int p = 10 - o;
+        const float C = Ce - Co, S = So - Se;
+        const float dc = (p & 1) ? dcm : dcp;
+        y[p] = (dc + (C - S)) * KH[p];
+        if (p < 10) y[20 - p] = (dc + (C + S)) * KH[20 - p];
+      }
+    }
+  }
+  const int g = f;
+  const bool interior = g >= 3 && g < Tf;  // frames g-3 .. g all exist
+  const int nout = Tf > 0 ? 5 * (Tf - 1) : 0;
+  const int ntot = 5 * (Tfmax - 1);
+  const bool mine = lane >= 3 && g < g0 + IW_HB;
+  float* wb = wav + (long long)b * wbs;
+  float v[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const float s3 = __shfl_up(y[15 + r], 3), s2 = __shfl_up(y[10 + r], 2), s1 = __shfl_up(y[5 + r], 1);
+    v[r] = ((s3 + s2) + s1) + y[r];  // ascending frame order (utils.py:138-147); frames outside [0, Tf) hold exact zeros
+  }
+  if (__ballot(mine && !interior) != 0ull) {  // an utterance edge inside this wave: partial window sums (utils.py:143-150)
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      float ws = 0.f;
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        const int fj = g - j;
+        if (fj >= 0 && fj < Tf) ws += tb.hann_per[5 * j + r];
+      }
+      if (!interior) {
+        const float a2 = v[r] + v[r];  // the literals carry the interior 1/2
+        v[r] = ws != 0.f ? a2 * __builtin_amdgcn_rcpf(ws) : a2;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int n = 5 * g + r - 10;
+    if (mine && n >= 0 && n < ntot) wb[n] = n < nout ? v[r] : 0.f;
+  }
+}
+
 const Tables g_tables = make_tables();
 
 }  // namespace
@@ -470,6 +606,17 @@ int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_f
   if (ldx < 22 || ldx > 64) return kk_fail("istft_head: input pitch must be in [22, 64]");
   static int tiled = -1;
   if (tiled < 0) tiled = getenv("KK_ISTFT_TILED") ? 1 : 0;  // A/B switch: the LDS-tiled kernel
+  static int oldfast = -1;
+  if (oldfast < 0) oldfast = getenv("KK_ISTFT_OLDFAST") ? 1 : 0;  // A/B switch: the generic wave kernel's FAST instantiation
+  if (!tiled && fast && !oldfast && 5LL * Tfmax < 0x7fffffffLL) {
+    dim3 gw(kk_cdiv(Tfmax + 3, 4 * IW_HB), B);
+    if (dtype == KK_F32)
+      hipLaunchKernelGGL((istft_head_wave_fast_kernel<float>), gw, dim3(256), 0, st, (const float*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    else
+      hipLaunchKernelGGL((istft_head_wave_fast_kernel<bf16_t>), gw, dim3(256), 0, st, (const bf16_t*)x, xbs, ldx, len_frames, Tfmax, wav, wbs, g_tables);
+    KK_CHECK_LAUNCH();
+    return 0;
+  }
   if (!tiled) {
     dim3 gw(kk_cdiv(Tfmax + 3, 4 * IW_HB), B);
     if (dtype == KK_F32) {

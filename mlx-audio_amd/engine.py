@@ -41,7 +41,8 @@ _NP2KK = {np.dtype(np.float32): _lib.KK_F32, np.dtype(np.float16): _lib.KK_F16}
 class KokoroEngine:
     """Owns a finalized kk_model on one GPU and runs batches of utterances through it."""
 
-    def __init__(self, cfg: dict, weights: Dict[str, np.ndarray], compute_dtype: str = "float32", device: Optional[torch.device] = None):
+    def __init__(self, cfg: dict, weights: Dict[str, np.ndarray], compute_dtype: str = "float32", device: Optional[torch.device] = None,
+                 quantization: Optional[dict] = None):
         if not torch.cuda.is_available():
             raise _lib.KokoroHipError("KokoroEngine needs a GPU (torch.cuda.is_available() is False)")
         self.lib = _lib.load()
@@ -51,6 +52,9 @@ class KokoroEngine:
         self._h = C.c_void_p()
         kc = make_kk_config(cfg, compute_dtype)
         check(self.lib.kk_create(C.byref(kc), C.byref(self._h)), "kk_create")
+        self.quantization = quantization
+        if quantization is not None:  # load_model's quantization branch (tts/utils.py:241-260): `weights` are the dequantised ones
+            check(self.lib.kk_set_quantization(self._h, int(quantization["group_size"]), int(quantization["bits"])), "kk_set_quantization")
         for name, arr in weights.items():
             self._load(name, arr)
         with torch.cuda.device(self.device):
@@ -187,7 +191,7 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ per-kernel-class timing (bench)
     PROFILE_CLASSES = ["conv_generic", "conv_mfma", "instnorm_stats", "adain_act", "lstm", "istft_head", "layernorm", "attention",
-                       "source", "stft"]
+                       "source", "stft", "linear_mxfp8"]
 
     def profile_begin(self, max_launches: int = 200000) -> None:
         check(self.lib.kk_profile_begin(self._h, max_launches), "kk_profile_begin")

@@ -52,7 +52,8 @@ class Model:
         audio: torch.Tensor
         pred_dur: Optional[torch.Tensor] = None
 
-    def __init__(self, config: ModelConfig, repo_id: str = None, weights: Optional[dict] = None, compute_dtype: str = "float32"):
+    def __init__(self, config: ModelConfig, repo_id: str = None, weights: Optional[dict] = None, compute_dtype: str = "float32",
+                 quantization: Optional[dict] = None):
         self.repo_id = repo_id
         self.config = config
         self.vocab = config.vocab
@@ -60,6 +61,7 @@ class Model:
         self._pipelines: Dict[str, "KokoroPipeline"] = {}
         self._engine: Optional[KokoroEngine] = None
         self._compute_dtype = compute_dtype
+        self._quantization = quantization  # config["quantization"] of an MLX 8-bit checkpoint (tts/utils.py:241-260)
         self._seed = 0
         if weights is not None:
             self.load_weights(weights)
@@ -77,7 +79,7 @@ class Model:
         g = items.get("decoder.encode.conv1.weight_g")  # width of the decoder blocks (1024 in Kokoro-82M, istftnet.py:917)
         if g is not None:
             cfg["decoder_hidden"] = int(g.shape[0])
-        self._engine = KokoroEngine(cfg, items, compute_dtype=self._compute_dtype)
+        self._engine = KokoroEngine(cfg, items, compute_dtype=self._compute_dtype, quantization=self._quantization)
         return self
 
     def sanitize(self, weights):

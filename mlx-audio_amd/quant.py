@@ -4,7 +4,8 @@
     scales  [O, I / group_size],  biases [O, I / group_size]              w ~= scales * q + biases  per group of `group_size` inputs
 This module dequantises such triplets at LOAD time; the arithmetic then runs on the bf16 MFMA path with exactly the weights MLX's
 `quantized_matmul` multiplies by.  The packing layout is upstream-MLX knowledge (MLX is not in the reference tree): PARITY UNPINNED.
-An fp8 MFMA path for these layers (~2 % of the forward's FLOPs) is not built."""
+In bf16 mode an 8-bit checkpoint's Linear set then runs on the block-scaled fp8 matrix instruction: the engine re-quantises the
+dequantised matrices to e4m3 with one power-of-two scale per group (kk_set_quantization, csrc/kk_mxfp8.hip)."""
 from __future__ import annotations
 
 from typing import Dict
@@ -57,4 +58,29 @@ def dequantize_checkpoint(weights: Dict[str, np.ndarray], group_size: int, bits:
                                        group_size, bits)
         else:
             out[k] = v
+    return out
+
+
+def quantised_layer_names(weights: Dict[str, np.ndarray], group_size: int = 64):
+    """The reference's class predicate (tts/utils.py:349-369 / :243-252) on a Kokoro checkpoint: nn.Linear / nn.Embedding weights
+    (2-D `*.weight`) whose element count is a multiple of 64 and whose input width is a multiple of the group size.  ConvWeighted,
+    the hand-rolled LSTM and nn.Conv1d hold raw arrays and stay as they are."""
+    names = []
+    for k, v in weights.items():
+        if not k.endswith(".weight") or np.ndim(v) != 2:  # LSTM matrices are named Wx_* / Wh_* (weight_ih_* on the PyTorch side)
+            continue
+        a = np.asarray(v)
+        if a.size % 64 == 0 and a.shape[1] % group_size == 0:
+            names.append(k)
+    return names
+
+
+def quantize_checkpoint(weights: Dict[str, np.ndarray], group_size: int = 64, bits: int = 8) -> Dict[str, np.ndarray]:
+    """What `convert(..., quantize=True)` leaves on disk for the layer set above: uint32-packed `weight`, `scales`, `biases`
+    (test fixtures and bench.py --quantized; the product path only ever DEquantises)."""
+    out = dict(weights)
+    for k in quantised_layer_names(weights, group_size):
+        words, scales, biases = quantize_affine(np.asarray(weights[k], np.float32), group_size, bits)
+        p = k[: -len(".weight")]
+        out[k], out[p + ".scales"], out[p + ".biases"] = words, scales, biases
     return out

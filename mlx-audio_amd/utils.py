@@ -90,6 +90,10 @@ def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtyp
                      (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))) for k, v in weights.items()}
         weights = dequantize_checkpoint(as_np, int(quantization["group_size"]), int(quantization["bits"]))
     cfg = arch.ModelConfig.from_dict(config)
-    model = arch.Model(cfg, compute_dtype=compute_dtype)
+    # an 8-bit checkpoint in bf16 mode runs its quantised linears on the fp8 matrix instruction (kk_set_quantization); other bit
+    # widths (and the fp32 parity mode) use the dequantised weights on the ordinary kernels
+    q8 = quantization if (quantization is not None and int(quantization["bits"]) == 8 and int(quantization["group_size"]) % 32 == 0
+                          and compute_dtype == "bfloat16") else None
+    model = arch.Model(cfg, compute_dtype=compute_dtype, quantization=q8)
     model.load_weights(weights, strict=strict)
     return model

@@ -402,6 +402,39 @@ def test_istft_head(lib):
         assert np.all(got[b, 5 * (n - 1) :] == 0)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_istft_head_fast_path(lib, dtype):
+    """The bf16 mode's iSTFT head (hardware exp / sin, polynomial sin / cos of the phase's sine, literal window tables, edge waves
+    only rebuild the window sum): same oracle, utterance lengths that put edges at every position of a wave's 61 hop blocks."""
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(8)
+    lens = [733, 1, 2, 3, 4, 5, 59, 60, 61, 62, 63, 64, 65, 122, 123, 244, 245, 246, 732]
+    B, Tf = len(lens), 733
+    x = (rng.standard_normal((B, Tf, 22)) * 1.5).astype(np.float32)
+    if dtype == "bf16":
+        x = torch.tensor(x).to(torch.bfloat16).float().numpy()
+    orc = _oracle_stub()
+    wav = torch.full((B, 5 * (Tf - 1)), 4.0, device="cuda")
+    ldx = 24  # the model's conv_post pitch (22 rounded up to 8)
+    xd = torch.zeros((B, Tf, ldx), dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, device="cuda")
+    xd[:, :, :22] = torch.tensor(x).to(xd.dtype)
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_istft_head(stream(), B, P(xd), ldx, Tf, P(lend), P(wav), _lib.KK_BF16 if dtype == "bf16" else _lib.KK_F32, 1)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got = wav.cpu().numpy()
+    worst = 0.0
+    for b, n in enumerate(lens):
+        if n > 1:
+            ref = orc.istft_head(np.transpose(x[b : b + 1, :n], (0, 2, 1)))[0, 0]
+            e = err_stats(got[b, : 5 * (n - 1)], ref)
+            worst = max(worst, e["rel_max"])
+            assert e["rel_max"] < 1e-4, (n, e)  # hardware exp / sin: ~1e-6 relative each; measured worst case reported below
+        assert np.all(got[b, 5 * (n - 1) :] == 0), n
+    report(f"istft_head_fast/{dtype}", worst_rel_max=worst)
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 MFMA convolution kernel
 # ------------------------------------------------------------------------------------------------
