@@ -252,6 +252,10 @@ void kk_csm_destroy(kk_csm* m);
  * post_attention_layernorm}.weight, {backbone,decoder}.norm.weight, text_embeddings.weight, audio_embeddings.weight,
  * projection.weight, codebook0_head.weight, audio_head [n_cb-1][decoder_dim][audio_vocab]; host fp32 */
 int kk_csm_load_tensor(kk_csm* m, const char* name, const int64_t* shape, int ndim, const float* data);
+/* weight storage of the Linear layers: KK_DTYPE_F32 (default) or KK_DTYPE_BF16 -- matrices rounded to bf16 once (lossless for the
+ * bf16 checkpoints load_model keeps in their own dtype, tts/utils.py:217-262), 2-byte weight stream in the single-token steps with
+ * SwiGLU applied while the down projection stages its input; activations, accumulation, KV cache, logits stay fp32.  Before finalize. */
+int kk_csm_set_weight_dtype(kk_csm* m, int dtype);
 int kk_csm_finalize(kk_csm* m, void* stream);
 int kk_csm_setup_caches(kk_csm* m, int max_batch); /* SesameModel.setup_caches (sesame.py:320-333): library-owned KV caches */
 int kk_csm_reset_caches(kk_csm* m);                /* sesame.py:338-345: positions restart at 0 */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "kk_csm_create": (_i, [C.POINTER(KKCsmConfig), C.POINTER(_vp)]),
     "kk_csm_destroy": (None, [_vp]),
     "kk_csm_load_tensor": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), _i, _vp]),
+    "kk_csm_set_weight_dtype": (_i, [_vp, _i]),
     "kk_csm_finalize": (_i, [_vp, _vp]),
     "kk_csm_setup_caches": (_i, [_vp, _i]),
     "kk_csm_reset_caches": (_i, [_vp]),

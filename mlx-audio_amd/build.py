@@ -20,6 +20,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+# per-file extras.  kk_source.hip: the iSTFT head is written on explicit register pairs (v_pk_*_f32); hipcc's SLP vectoriser otherwise
+# re-pairs the scalar tail across outputs and pays two v_mov per packed op it creates
+FILE_FLAGS = {"kk_source.hip": ["-fno-slp-vectorize"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -33,6 +38,7 @@ def _digest() -> str:
             h.update(open(p, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "kokoro_hip.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -47,7 +53,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = 
 
     def cc(src):
         obj = os.path.join(OBJ, src[:-4] + ".o")
-        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

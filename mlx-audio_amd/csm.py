@@ -23,7 +23,7 @@ def _llama_args(d: dict) -> _lib.KKLlamaArgs:
 
 
 class SesameModel:
-    def __init__(self, cfg: dict, weights: Optional[Dict[str, np.ndarray]] = None, device: str = "cuda:0"):
+    def __init__(self, cfg: dict, weights: Optional[Dict[str, np.ndarray]] = None, device: str = "cuda:0", weight_dtype: str = "float32"):
         self.cfg = cfg
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -36,6 +36,11 @@ class SesameModel:
         h = C.c_void_p()
         check(self.lib.kk_csm_create(C.byref(kc), C.byref(h)), "kk_csm_create")
         self._h = h
+        # "bfloat16": what load_model does for a bf16 checkpoint (it keeps the checkpoint's dtype, tts/utils.py:217-262) -- the Linear
+        # matrices are stored as bf16 and streamed as such by the single-token steps; arithmetic stays fp32
+        self.weight_dtype = weight_dtype
+        if weight_dtype != "float32":
+            check(self.lib.kk_csm_set_weight_dtype(self._h, {"bfloat16": _lib.KK_BF16}[weight_dtype]), "kk_csm_set_weight_dtype")
         self._final = False
         self._ws = None
         self._enabled = False

@@ -25,6 +25,9 @@ struct Lin {  // generic-kernel pack [1][Cin][ldw]
   size_t off = 0;
   int Cin = 0, Cout = 0, ldw = 0;
   const float* w = nullptr;
+  // bf16 weight mode (kk_csm_set_weight_dtype): the same matrix as bf16 [Cin][ldw] for the single-token skinny GEMM
+  size_t boff = 0;
+  const uint16_t* wb = nullptr;
 };
 struct Vec {
   size_t off = 0;
@@ -53,6 +56,9 @@ struct kk_csm {
   std::vector<float> pack;
   float* dev = nullptr;
   bool finalized = false;
+  int wdt = KK_F32;              // weight storage of the single-token steps (KK_F32 / KK_BF16)
+  std::vector<uint16_t> packb;   // host staging of the bf16 copies
+  uint16_t* devb = nullptr;
   Stack bb, dec;
   Vec text_emb, audio_emb;
   Lin proj, c0_head;
@@ -258,49 +264,90 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int V,
   }
 }
 
-// Skinny GEMM for the single-token steps (M = B rows <= 16): out[m][n] = sum_k x[m][k] W[k][n].  HBM-bound on W, so the grid is
-// (N / 256 column blocks) x (KS slices of K): every thread streams ONE column of its K slice with coalesced row reads and keeps
-// M accumulators; the slices' partial sums are added in slice order by the second kernel (deterministic, residual fused).
+// Skinny GEMM for the single-token steps (M = B rows <= 16): out[m][n] = sum_k x[m][k] W[k][n].  The grid is (column blocks) x (KS
+// slices of K): every thread streams ONE column (fp32 weights) or TWO adjacent columns (bf16 weights, one 4-byte load) of its K slice
+// with coalesced row reads, 16 loads in flight; the slices' partial sums are added in slice order by the second kernel
+// (deterministic, residual fused).  The rows are held as PACKED PAIRS: xs[k][m] keeps the M activations of one k adjacent, so a
+// weight meets rows (2i, 2i+1) in one v_pk_fma_f32 -- MT/2 packed FMAs per weight (MT = 8 or 16 rows, a template parameter).  The
+// first version issued 16 predicated scalar FMAs per weight whatever M was and was VALU-bound (K*N*16 lane-FMAs: 13.6 us for the
+// backbone's gate|up matrix against a 13 us HBM floor in bf16), which is why halving the weight bytes did not pay before.
+// `GATED`: x is the gate|up pair of a SwiGLU MLP ([M][2K]) and the staged input is silu(gate) * up (the stand-alone swiglu kernel of
+// the single-token step disappears).
 constexpr int SK_MAXM = 16, SK_KC = 256;
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* x, int M, int K, const float* w, int ldw, int N, int kchunk, float* part) {
-  __shared__ float xs[SK_MAXM][SK_KC];
-  const int n = blockIdx.x * 256 + threadIdx.x, ks = blockIdx.y;
+typedef float sk2f __attribute__((ext_vector_type(2)));
+template <int MT, bool BF16W, bool GATED>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* x, int M, int K, const void* wv_, int ldw, int N, int kchunk, float* part) {
+  constexpr int NC = BF16W ? 2 : 1;  // columns per thread
+  constexpr int MP = MT / 2;         // row pairs
+  __shared__ __attribute__((aligned(16))) float xs[SK_KC][MT];
+  const int n = (blockIdx.x * 256 + threadIdx.x) * NC, ks = blockIdx.y;
   const int k0 = ks * kchunk, k1 = min(K, k0 + kchunk);
-  float acc[SK_MAXM];
+  sk2f acc[NC][MP];
 #pragma unroll
-  for (int m = 0; m < SK_MAXM; ++m) acc[m] = 0.f;
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int i = 0; i < MP; ++i) acc[c][i] = sk2f{0.f, 0.f};
   for (int kb = k0; kb < k1; kb += SK_KC) {
     const int kn = min(SK_KC, k1 - kb);
     __syncthreads();
-    for (int e = threadIdx.x; e < M * kn; e += 256) {
-      const int m = e / kn, k = e - m * kn;
-      xs[m][k] = x[(long long)m * K + kb + k];
+    for (int e = threadIdx.x; e < MT * kn; e += 256) {
+      const int m = e / kn, k = e - m * kn;  // consecutive threads read consecutive k of one row
+      float v = 0.f;
+      if (m < M) {
+        if (GATED) {
+          const float g = x[(long long)m * 2 * K + kb + k], u = x[(long long)m * 2 * K + K + kb + k];
+          v = g / (1.0f + expf(-g)) * u;
+        } else {
+          v = x[(long long)m * K + kb + k];
+        }
+      }
+      xs[k][m] = v;
     }
     __syncthreads();
     if (n < N) {
-      const float* wp = w + (long long)kb * ldw + n;
+      const unsigned* wp = BF16W ? (const unsigned*)((const uint16_t*)wv_ + (long long)kb * ldw + n) : (const unsigned*)((const float*)wv_ + (long long)kb * ldw + n);
+      const long long ldq = BF16W ? (ldw >> 1) : ldw;  // row pitch in 4-byte words
+      auto fma_k = [&](unsigned wbits, int k) {
+        const sk2f* xr = (const sk2f*)&xs[k][0];
+        if (BF16W) {
+          const float w0 = __uint_as_float(wbits << 16), w1 = __uint_as_float(wbits & 0xffff0000u);
+#pragma unroll
+          for (int i = 0; i < MP; ++i) {
+            const sk2f xv = xr[i];
+            acc[0][i] = __builtin_elementwise_fma(xv, sk2f{w0, w0}, acc[0][i]);
+            acc[NC - 1][i] = __builtin_elementwise_fma(xv, sk2f{w1, w1}, acc[NC - 1][i]);
+          }
+        } else {
+          const float w0 = __uint_as_float(wbits);
+#pragma unroll
+          for (int i = 0; i < MP; ++i) acc[0][i] = __builtin_elementwise_fma(xr[i], sk2f{w0, w0}, acc[0][i]);
+        }
+      };
       int k = 0;
-      for (; k + 16 <= kn; k += 16) {  // 16 independent loads in flight per thread: the kernel is latency-bound otherwise
-        float wv[16];
+      for (; k + 16 <= kn; k += 16) {  // 16 independent loads in flight per thread
+        unsigned wv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wv[j] = wp[(long long)(k + j) * ldw];
+        for (int j = 0; j < 16; ++j) wv[j] = wp[(long long)(k + j) * ldq];
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-#pragma unroll
-          for (int m = 0; m < SK_MAXM; ++m)
-            if (m < M) acc[m] = __builtin_fmaf(xs[m][k + j], wv[j], acc[m]);
+        for (int j = 0; j < 16; ++j) fma_k(wv[j], k + j);
       }
-      for (; k < kn; ++k) {
-        const float wv = wp[(long long)k * ldw];
+      for (; k < kn; ++k) fma_k(wp[(long long)k * ldq], k);
+    }
+  }
+  if (n < N) {
 #pragma unroll
-        for (int m = 0; m < SK_MAXM; ++m)
-          if (m < M) acc[m] = __builtin_fmaf(xs[m][k], wv, acc[m]);
+    for (int c = 0; c < NC; ++c) {
+      if (n + c >= N) continue;
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+        // slices of one output element are contiguous
+        if (2 * i < M) part[((long long)(2 * i) * N + n + c) * gridDim.y + ks] = acc[c][i].x;
+        if (2 * i + 1 < M) part[((long long)(2 * i + 1) * N + n + c) * gridDim.y + ks] = acc[c][i].y;
       }
     }
   }
-  if (n < N)
-    for (int m = 0; m < M; ++m) part[((long long)m * N + n) * gridDim.y + ks] = acc[m];  // slices of one output element are contiguous
 }
+
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, int KS, int M, int N, const float* res, float* out) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)M * N) return;
@@ -375,6 +422,22 @@ struct Packer {
       }
       base += outs[k];
     }
+    if (m->wdt == KK_BF16) {
+      // bf16 weight mode: the matrix IS its bf16 rounding everywhere (the fp32 pack the multi-token prompt block reads holds the rounded
+      // values too, so a prompt block and single-token steps multiply by identical weights); lossless for a bf16 checkpoint
+      l.boff = m->packb.size();
+      m->packb.resize(l.boff + (size_t)I * l.ldw, 0);
+      float* dst = &m->pack[l.off];
+      uint16_t* db = &m->packb[l.boff];
+      for (size_t e = 0; e < (size_t)I * l.ldw; ++e) {
+        uint32_t u;
+        memcpy(&u, &dst[e], 4);
+        if ((u & 0x7FFFFFFFu) <= 0x7F800000u) u += 0x7FFFu + ((u >> 16) & 1u);
+        db[e] = (uint16_t)(u >> 16);
+        u &= 0xFFFF0000u;
+        memcpy(&dst[e], &u, 4);
+      }
+    }
     return l;
   }
 };
@@ -426,7 +489,10 @@ void pack_stack(Packer& P, const std::string& name, Stack& st, int max_pos) {
     }
 }
 
-void resolve(kk_csm* m, Lin& l) { l.w = m->dev + l.off; }
+void resolve(kk_csm* m, Lin& l) {
+  l.w = m->dev + l.off;
+  l.wb = m->devb ? m->devb + l.boff : nullptr;
+}
 void resolve(kk_csm* m, Vec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_csm* m, Stack& st) {
   for (auto& L : st.layers) { resolve(m, L.qkv); resolve(m, L.o); resolve(m, L.gu); resolve(m, L.down); resolve(m, L.n1); resolve(m, L.n2); }
@@ -450,8 +516,14 @@ struct Run {
     return (float*)(base + off);
   }
   // out[b][row][:] = W x[b][row][:] (+ res); x rows: `rows` per item at pitch `xbs` elements between items
-  int lin(const Lin& w, const float* x, long long xbs, int rows, float* out, long long obs, const float* res) {
+  // `gated`: x is [.. rows][2 * Cin] = gate | up and the input of the product is silu(gate) * up (skinny bf16 path only; callers check
+  // can_gate() first and run the stand-alone swiglu kernel otherwise).  `nw` / `xn`: RMSNorm of the result rows, launched right behind.
+  bool can_gate(const Lin& w, int rows) const { return w.wb && rows <= 2 && skinny_scratch != nullptr; }
+  int lin(const Lin& w, const float* x, long long xbs, int rows, float* out, long long obs, const float* res, bool gated = false,
+          const float* nw = nullptr, float* xn = nullptr, float eps = 0.f) {
     if (dry) return 0;
+    if (gated && !(can_gate(w, rows) && xbs == (long long)rows * 2 * w.Cin && obs == (long long)rows * w.Cout)) return kk_fail("kk_csm: internal: gated input");
+    if (gated) xbs = (long long)rows * w.Cin;
     KKConvArgs a;
     memset(&a, 0, sizeof a);
     a.x = x; a.xbs = xbs; a.ldx = w.Cin; a.w = w.w; a.ldw = w.ldw;
@@ -464,8 +536,8 @@ struct Run {
     if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && rows <= 2 && skinny_scratch) {
       // single-token steps (and the decoder's 2-token first step): the HBM-bound skinny GEMM (every CU streams a slice of W once for up
       // to 16 rows).  The choice depends on the rows PER ITEM only, never on B, so a stream's bits do not depend on its batch.
-      const int Mtot = B * rows, nblk = kk_cdiv(w.Cout, 256);
-      int KS = 1024 / nblk;  // ~4 workgroups per CU (measured: fewer, longer slices are slower -- the kernel is latency-bound)
+      const int Mtot = B * rows, nblk256 = kk_cdiv(w.Cout, 256), nblk = w.wb ? kk_cdiv(w.Cout, 512) : nblk256;
+      int KS = 1024 / nblk256;  // ~4 workgroups per CU (measured: fewer, longer slices are slower -- the kernel is latency-bound)
       int maxks = kk_cdiv(w.Cin, 32);
       if (maxks > 64) maxks = 64;
       KS = KS < 1 ? 1 : (KS > maxks ? maxks : KS);
@@ -474,10 +546,23 @@ struct Run {
       if ((size_t)KS * SK_MAXM * w.Cout <= skinny_floats) {
         for (int m0 = 0; m0 < Mtot; m0 += SK_MAXM) {
           const int M = Mtot - m0 < SK_MAXM ? Mtot - m0 : SK_MAXM;
-          hipLaunchKernelGGL(skinny_gemm_kernel, dim3(nblk, KS), dim3(256), 0, st, x + (size_t)m0 * w.Cin, M, w.Cin, w.w, w.ldw, w.Cout, kchunk, skinny_scratch);
+          const float* xin = x + (size_t)m0 * (gated ? 2 : 1) * w.Cin;
+          const dim3 g(nblk, KS), t(256);
+#define SK_GO(MT, BW, GT) hipLaunchKernelGGL((skinny_gemm_kernel<MT, BW, GT>), g, t, 0, st, xin, M, w.Cin, BW ? (const void*)w.wb : (const void*)w.w, w.ldw, w.Cout, kchunk, skinny_scratch)
+          // MT depends on the rows per launch only through "fits in 8": a row's arithmetic is the same in both instantiations
+          if (M <= 8) {
+            if (w.wb && gated) SK_GO(8, true, true); else if (w.wb) SK_GO(8, true, false); else SK_GO(8, false, false);
+          } else {
+            if (w.wb && gated) SK_GO(16, true, true); else if (w.wb) SK_GO(16, true, false); else SK_GO(16, false, false);
+          }
+#undef SK_GO
           KK_CHECK_LAUNCH();
           hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)(((long long)M * w.Cout + 255) / 256)), dim3(256), 0, st, skinny_scratch, KS, M, w.Cout,
                              res ? res + (size_t)m0 * w.Cout : nullptr, out + (size_t)m0 * w.Cout);
+          KK_CHECK_LAUNCH();
+        }
+        if (xn) {
+          hipLaunchKernelGGL(rmsnorm_kernel, dim3(Mtot), dim3(256), 0, st, out, nw, w.Cout, eps, xn);
           KK_CHECK_LAUNCH();
         }
         return 0;
@@ -491,7 +576,12 @@ struct Run {
       a.xbs = a.obs = a.rbs = 0;
       nb = 1;
     }
-    return kk_launch_conv_generic(a, nb, KK_F32, KK_F32, st);
+    const int rc = kk_launch_conv_generic(a, nb, KK_F32, KK_F32, st);
+    if (rc != 0 || !xn) return rc;
+    if (obs != (long long)rows * w.Cout) return kk_fail("kk_csm: internal: norm of a strided result");
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * rows), dim3(256), 0, st, out, nw, w.Cout, eps, xn);
+    KK_CHECK_LAUNCH();
+    return 0;
   }
 };
 
@@ -513,14 +603,15 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
   float* act = r.f32((size_t)B * S * I);
   if (r.oom) return kk_fail("kk_csm: workspace too small");
   if (!r.dry && offset + S > st.max_pos) return kk_fail("kk_csm: sequence exceeds the cache (max_seq_len)");
+  // x = RMSNorm(h) of the CURRENT layer's input: stand-alone for layer 0, afterwards produced by the previous down projection's tail
+  if (!r.dry) {
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, st.layers[0].n1.p, D, a.rms_eps, x);
+    KK_CHECK_LAUNCH();
+  }
   for (int l = 0; l < a.num_layers; ++l) {
     const LlamaLayer& L = st.layers[l];
     float* kc = st.kc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
     float* vc = st.vc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
-    if (!r.dry) {
-      hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, L.n1.p, D, a.rms_eps, x);
-      KK_CHECK_LAUNCH();
-    }
     CS_TRY(r.lin(L.qkv, x, (long long)S * D, S, qkv, (long long)S * W, nullptr));
     if (!r.dry) {
       hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
@@ -529,22 +620,23 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
                          vc, st.max_pos, 1.0f / sqrtf((float)hd), att);
       KK_CHECK_LAUNCH();
     }
-    CS_TRY(r.lin(L.o, att, (long long)S * H * hd, S, h, (long long)S * D, h));
-    if (!r.dry) {
-      hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, L.n2.p, D, a.rms_eps, x);
-      KK_CHECK_LAUNCH();
-    }
+    // h += o(att); x = RMSNorm(h) (post_attention_layernorm)
+    CS_TRY(r.lin(L.o, att, (long long)S * H * hd, S, h, (long long)S * D, h, false, L.n2.p, x, a.rms_eps));
     CS_TRY(r.lin(L.gu, x, (long long)S * D, S, gu, (long long)S * 2 * I, nullptr));
-    if (!r.dry) {
-      const long long n = (long long)B * S * I;
-      hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, gu, I, n, act);
-      KK_CHECK_LAUNCH();
+    // h += down(silu(gate) * up); then the NEXT consumer's norm: the next layer's input_layernorm -> x, or the stack's final norm -> out
+    const bool lastl = l + 1 == a.num_layers;
+    const float* nw = lastl ? st.norm.p : st.layers[l + 1].n1.p;
+    float* xn = lastl ? out : x;
+    if (r.can_gate(L.down, S)) {  // bf16 weight mode, single-token step: SwiGLU is applied while the down projection stages its input
+      CS_TRY(r.lin(L.down, gu, (long long)S * 2 * I, S, h, (long long)S * D, h, true, nw, xn, a.rms_eps));
+    } else {
+      if (!r.dry) {
+        const long long n = (long long)B * S * I;
+        hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, gu, I, n, act);
+        KK_CHECK_LAUNCH();
+      }
+      CS_TRY(r.lin(L.down, act, (long long)S * I, S, h, (long long)S * D, h, false, nw, xn, a.rms_eps));
     }
-    CS_TRY(r.lin(L.down, act, (long long)S * I, S, h, (long long)S * D, h));
-  }
-  if (!r.dry) {
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * S), dim3(256), 0, r.st, h, st.norm.p, D, a.rms_eps, out);
-    KK_CHECK_LAUNCH();
   }
   return 0;
 }
@@ -574,9 +666,10 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   size_t peak = r.used;
   r.used = inner;  // the stack's scratch is free again
   const float* last_h = hn ? hn + (size_t)(S - 1) * D : nullptr;  // row S-1 of every item (pitch S*D)
+  // the heads write their logits straight into the slot kk_csm_debug_logits reads ([n_cb][maxB][V], first B rows): no copy per code book
+  if (!r.dry && m->dbg_logits) logits = m->dbg_logits;
   CS_TRY(r.lin(m->c0_head, last_h, (long long)S * D, 1, logits, V, nullptr));
   if (!r.dry) {
-    if (m->dbg_logits && hipMemcpyAsync(m->dbg_logits, logits, (size_t)B * V * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_csm: copy failed");
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), (size_t)V * 4, r.st, logits, V, temp, top_k, uniforms, ncb, codes, ncb);
     KK_CHECK_LAUNCH();
     // curr = [last_h, embed_audio(0, c0)]
@@ -593,10 +686,9 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
     if (r.used > peak) peak = r.used;
     dpos += rows;
     const float* dl = dn ? dn + (size_t)(rows - 1) * Dd : nullptr;
+    if (!r.dry && m->dbg_logits) logits = m->dbg_logits + (size_t)i * m->max_batch * V;
     CS_TRY(r.lin(m->audio_head[i - 1], dl, (long long)rows * Dd, 1, logits, V, nullptr));
     if (!r.dry) {
-      if (m->dbg_logits && hipMemcpyAsync(m->dbg_logits + (size_t)i * m->max_batch * V, logits, (size_t)B * V * 4, hipMemcpyDeviceToDevice, r.st) != hipSuccess)
-        return kk_fail("kk_csm: copy failed");
       hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), (size_t)V * 4, r.st, logits, V, temp, top_k, uniforms ? uniforms + i : nullptr, ncb, codes + i, ncb);
       KK_CHECK_LAUNCH();
       hipLaunchKernelGGL(embed_audio_kernel, dim3(B), dim3(256), 0, r.st, codes + i, ncb, m->audio_emb.p, i, V, D, curr, 1, 0);
@@ -638,6 +730,7 @@ extern "C" int kk_csm_create(const kk_csm_config* cfg, kk_csm** out) {
 extern "C" void kk_csm_destroy(kk_csm* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
+  if (m->devb) (void)hipFree(m->devb);
   for (Stack* s : {&m->bb, &m->dec}) {
     if (s->kc) (void)hipFree(s->kc);
     if (s->vc) (void)hipFree(s->vc);
@@ -650,6 +743,18 @@ extern "C" void kk_csm_destroy(kk_csm* m) {
   }
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   delete m;
+}
+
+// Weight storage of the linears in the single-token steps.  KK_DTYPE_BF16: every Linear matrix is rounded to bf16 once (lossless for a
+// bf16 checkpoint -- the reference keeps the checkpoint's dtype, tts/utils.py:217-262) and the skinny GEMM streams 2-byte weights (half
+// the bytes per frame; the 212 MB depth decoder then fits the 256 MB Infinity Cache across its 31 steps); activations, accumulation,
+// KV cache and logits stay fp32.  Call before kk_csm_finalize.
+extern "C" int kk_csm_set_weight_dtype(kk_csm* m, int dtype) {
+  if (!m) return kk_fail("kk_csm_set_weight_dtype: null model");
+  if (m->finalized) return kk_fail("kk_csm_set_weight_dtype: call before kk_csm_finalize");
+  if (dtype != KK_DTYPE_F32 && dtype != KK_DTYPE_BF16) return kk_fail("kk_csm_set_weight_dtype: F32 or BF16");
+  m->wdt = dtype == KK_DTYPE_BF16 ? KK_BF16 : KK_F32;
+  return 0;
 }
 
 extern "C" int kk_csm_load_tensor(kk_csm* m, const char* name, const int64_t* shape, int ndim, const float* data) {
@@ -683,11 +788,17 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
   if (hipMalloc((void**)&m->dev, m->pack.size() * sizeof(float)) != hipSuccess) return kk_fail("kk_csm_finalize: hipMalloc failed");
   if (hipMemcpyAsync(m->dev, m->pack.data(), m->pack.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
     return kk_fail("kk_csm_finalize: upload failed");
+  if (!m->packb.empty()) {
+    if (hipMalloc((void**)&m->devb, m->packb.size() * 2) != hipSuccess) return kk_fail("kk_csm_finalize: hipMalloc failed");
+    if (hipMemcpyAsync(m->devb, m->packb.data(), m->packb.size() * 2, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+      return kk_fail("kk_csm_finalize: upload failed");
+  }
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: stream sync failed");
   resolve(m, m->bb); resolve(m, m->dec); resolve(m, m->text_emb); resolve(m, m->audio_emb); resolve(m, m->proj); resolve(m, m->c0_head);
   for (auto& l : m->audio_head) resolve(m, l);
   m->host.clear();
   std::vector<float>().swap(m->pack);
+  std::vector<uint16_t>().swap(m->packb);
   m->finalized = true;
   return 0;
 }

@@ -471,13 +471,15 @@ __global__ __launch_bounds__(256) void istft_head_wave_fast_kernel(const T* x, l
   const int f = g0 - 3 + lane;
   const bool fv = f >= 0 && f < Tf;
   float y[20];
-#pragma unroll
-  for (int o = 0; o < 20; ++o) y[o] = 0.f;
-  if (fv) {
-    const T* xr = x + (long long)b * xbs + (long long)f * ldx;
+  {
+    // every lane runs the arithmetic (no divergence, no zero-initialised outputs): frames outside [0, Tf) read a clamped row -- finite
+    // data: rows past an utterance's length hold zeros -- and their magnitudes are multiplied by 0, which makes all 20 samples exact zeros
+    const int fc = min(max(f, 0), Tfmax - 1);
+    const float fmask = fv ? 1.0f : 0.0f;
+    const T* xr = x + (long long)b * xbs + (long long)fc * ldx;
     float in[22];
     if (sizeof(T) == 2 && (ldx & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)xbs * 2)) & 15) == 0) {
-      uint4 r[3];
+      uint4 r[3];  // 22 bf16 = 44 bytes: three 16-byte loads (the row pitch is >= 24 elements)
 #pragma unroll
       for (int q = 0; q < 3; ++q) r[q] = *((const uint4*)xr + q);
       const unsigned w[12] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w};
@@ -490,51 +492,59 @@ __global__ __launch_bounds__(256) void istft_head_wave_fast_kernel(const T* x, l
 #pragma unroll
       for (int k = 0; k < 22; ++k) in[k] = kk_ld(xr + k);
     }
-    float re[11], im[11];
+    // bins in PAIRS (2p, 2p+1): every stage below is packed fp32 math on register pairs, and the pair is exactly the (even k, odd k)
+    // split the o <-> 10-o symmetry of the inverse DFT needs, so no value ever has to be moved into a pair.  Bin 11 does not exist:
+    // its slot carries zeros and zero twiddles.
+    v2f re2[6], im2[6];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float mag = __expf(in[k]);
-      const float ph = __sinf(in[11 + k]);
-      // cos(ph), sin(ph) for |ph| <= 1: Taylor to ph^10 / ph^11 (truncation < 3e-9) as ONE packed Horner chain over the pair --
-      // five v_pk_fma_f32 instead of two quarter-rate v_sin / v_cos, and (re, im) come out as a register pair
-      const float t = ph * ph;
-      v2f acc = {-2.7557319223985888e-07f, -2.505210838544172e-08f};
-      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{2.48015873015873e-05f, 2.7557319223985893e-06f});
-      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{-1.3888888888888889e-03f, -1.984126984126984e-04f});
-      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{4.1666666666666664e-02f, 8.333333333333333e-03f});
-      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{-0.5f, -1.6666666666666666e-01f});
-      acc = __builtin_elementwise_fma(acc, v2f{t, t}, v2f{1.0f, 1.0f});
-      const v2f ri = acc * v2f{mag, mag * ph};
-      re[k] = ri.x;
-      im[k] = (k == 0 || k == 10) ? 0.f : ri.y;  // the inverse real FFT ignores the imaginary part of DC / Nyquist
+    for (int p = 0; p < 6; ++p) {
+      const v2f lm = {in[2 * p], p < 5 ? in[2 * p + 1] : 0.f};
+      const v2f pr = {in[11 + 2 * p], p < 5 ? in[12 + 2 * p] : 0.f};
+      const v2f mag = v2f{__expf(lm.x), __expf(lm.y)} * v2f{fmask, fmask};
+      const v2f ph = {__sinf(pr.x), __sinf(pr.y)};
+      // cos(ph), sin(ph) / ph for |ph| <= 1: Taylor to ph^10 (truncation < 3e-9), Horner in t = ph^2
+      const v2f t = ph * ph;
+      v2f c = v2f{-2.7557319223985888e-07f, -2.7557319223985888e-07f};
+      c = __builtin_elementwise_fma(c, t, v2f{2.48015873015873e-05f, 2.48015873015873e-05f});
+      c = __builtin_elementwise_fma(c, t, v2f{-1.3888888888888889e-03f, -1.3888888888888889e-03f});
+      c = __builtin_elementwise_fma(c, t, v2f{4.1666666666666664e-02f, 4.1666666666666664e-02f});
+      c = __builtin_elementwise_fma(c, t, v2f{-0.5f, -0.5f});
+      c = __builtin_elementwise_fma(c, t, v2f{1.0f, 1.0f});
+      v2f sn = v2f{-2.505210838544172e-08f, -2.505210838544172e-08f};
+      sn = __builtin_elementwise_fma(sn, t, v2f{2.7557319223985893e-06f, 2.7557319223985893e-06f});
+      sn = __builtin_elementwise_fma(sn, t, v2f{-1.984126984126984e-04f, -1.984126984126984e-04f});
+      sn = __builtin_elementwise_fma(sn, t, v2f{8.333333333333333e-03f, 8.333333333333333e-03f});
+      sn = __builtin_elementwise_fma(sn, t, v2f{-1.6666666666666666e-01f, -1.6666666666666666e-01f});
+      sn = __builtin_elementwise_fma(sn, t, v2f{1.0f, 1.0f});
+      re2[p] = mag * c;
+      im2[p] = (mag * ph) * sn;
     }
-    const float dcp = re[0] + re[10], dcm = re[0] - re[10];
+    // x[o] = sum_k w_k (re_k cos(2 pi k o / 20) - im_k sin(2 pi k o / 20)), w = 1 for DC / Nyquist (whose imaginary parts the inverse
+    // real FFT ignores: zero twiddles), 2 otherwise; (Ce, Co) / (Se, So) = the even-k / odd-k partial sums = the two halves of one
+    // packed accumulator; outputs o, 20-o, 10-o, 10+o share them.
 #pragma unroll
     for (int o = 0; o <= 5; ++o) {
-      float Ce = 0.f, Co = 0.f, Se = 0.f, So = 0.f;
+      v2f Cp = {0.f, 0.f}, Sp = {0.f, 0.f};
 #pragma unroll
-      for (int k = 1; k < 10; ++k) {
-        const int m = (k * o) % 20;
-        if (k & 1) {
-          Co = __builtin_fmaf(re[k], CS2[m], Co);
-          So = __builtin_fmaf(im[k], SN2[m], So);
-        } else {
-          Ce = __builtin_fmaf(re[k], CS2[m], Ce);
-          Se = __builtin_fmaf(im[k], SN2[m], Se);
+      for (int p = 0; p < 6; ++p) {
+        const int k0 = 2 * p, k1 = 2 * p + 1;
+        const v2f cc = {k0 == 0 ? 1.0f : (k0 == 10 ? ((o & 1) ? -1.0f : 1.0f) : CS2[(k0 * o) % 20]), k1 > 10 ? 0.0f : CS2[(k1 * o) % 20]};
+        Cp = __builtin_elementwise_fma(re2[p], cc, Cp);
+        if (p < 5 && o > 0) {  // o = 0: every sine twiddle is zero
+          const v2f ss = {k0 == 0 ? 0.0f : SN2[(k0 * o) % 20], SN2[(k1 * o) % 20]};
+          Sp = __builtin_elementwise_fma(im2[p], ss, Sp);
         }
       }
       {
-        const float C = Ce + Co, S = Se + So;
-        const float dc = (o & 1) ? dcm : dcp;
-        y[o] = (dc + (C - S)) * KH[o];
-        if (o > 0) y[20 - o] = (dc + (C + S)) * KH[20 - o];
+        const float C = Cp.x + Cp.y, S = Sp.x + Sp.y;
+        y[o] = (C - S) * KH[o];
+        if (o > 0) y[20 - o] = (C + S) * KH[20 - o];
       }
       if (o < 5) {
         const int p = 10 - o;
-        const float C = Ce - Co, S = So - Se;
-        const float dc = (p & 1) ? dcm : dcp;
-        y[p] = (dc + (C - S)) * KH[p];
-        if (p < 10) y[20 - p] = (dc + (C + S)) * KH[20 - p];
+        const float C = Cp.x - Cp.y, S = Sp.y - Sp.x;
+        y[p] = (C - S) * KH[p];
+        if (p < 10) y[20 - p] = (C + S) * KH[20 - p];
       }
     }
   }

@@ -38,15 +38,25 @@ def _prompt(cfg, rng, B, n_text, n_audio):
     return tok, msk
 
 
-def test_csm_tiny_frames_match_oracle():
+def _as_bf16_checkpoint(w):
+    """What a bf16 checkpoint holds: every tensor rounded to bf16 (load_model keeps the checkpoint's dtype, tts/utils.py:217-262)."""
+    return {k: torch.tensor(np.asarray(v, np.float32)).to(torch.bfloat16).float().numpy() for k, v in w.items()}
+
+
+@pytest.mark.parametrize("wdt", ["float32", "bfloat16"])
+def test_csm_tiny_frames_match_oracle(wdt):
+    """wdt = bfloat16: the Linear matrices are stored and streamed as bf16 (kk_csm_set_weight_dtype; SwiGLU fused into the down
+    projection's input staging); on a bf16 checkpoint that is lossless, so the bar against the fp32-arithmetic oracle is unchanged."""
     from mlx_audio_amd.csm import SesameModel
 
     cfg = P.csm_tiny_config()
     w = P.csm_synth_checkpoint(cfg, 0)
+    if wdt == "bfloat16":
+        w = _as_bf16_checkpoint(w)
     rng = np.random.default_rng(7)
     B, n = 3, cfg["audio_num_codebooks"]
     orc = C.CsmOracle(w, cfg)
-    model = SesameModel(cfg, w)
+    model = SesameModel(cfg, w, weight_dtype=wdt)
     model.setup_caches(B)
     tok, msk = _prompt(cfg, rng, B, 5, 3)
     frames = []
@@ -69,7 +79,7 @@ def test_csm_tiny_frames_match_oracle():
         lg = model.debug_logits().cpu().numpy()
         ref_lg = np.stack([trace["c0_logits"]] + trace["ci_logits"], 0)
         e = err_stats(lg, ref_lg)
-        report(f"csm/tiny/frame{step}/logits", **e)
+        report(f"csm/tiny/{wdt}/frame{step}/logits", **e)
         assert e["rel_max"] < 2e-4, (step, e)
         np.testing.assert_array_equal(got.cpu().numpy(), ref)
         assert model.position == orc.backbone.offset
@@ -82,7 +92,8 @@ def test_csm_tiny_frames_match_oracle():
         model.generate_frame(torch.tensor(tok), torch.tensor(msk))
 
 
-def test_csm_streams_are_independent_bitexact():
+@pytest.mark.parametrize("wdt", ["float32", "bfloat16"])
+def test_csm_streams_are_independent_bitexact(wdt):
     """A stream produces the same logits alone (B = 1) and next to others (B = 3), prompt block and single-token frames."""
     from mlx_audio_amd.csm import SesameModel
 
@@ -93,7 +104,7 @@ def test_csm_streams_are_independent_bitexact():
     tok, msk = _prompt(cfg, rng, 3, 6, 2)
 
     def run(sel):
-        model = SesameModel(cfg, w)
+        model = SesameModel(cfg, w, weight_dtype=wdt)
         model.setup_caches(len(sel))
         outs = []
         c = model.generate_frame(torch.tensor(tok[sel]), torch.tensor(msk[sel]))

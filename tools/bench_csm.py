@@ -19,12 +19,13 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--prompt", type=int, default=64)
 ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--e2e", action="store_true", help="config 4 end to end: reference-audio prompt (Mimi.encode) -> frame loop -> Mimi.decode")
+ap.add_argument("--weights", default="float32", choices=["float32", "bfloat16"], help="weight storage of the Linear layers (kk_csm_set_weight_dtype)")
 a = ap.parse_args()
 cfg = P.csm_config()
 t0 = time.time()
 w = P.csm_synth_checkpoint(cfg, 0)
 t1 = time.time()
-model = SesameModel(cfg, w)
+model = SesameModel(cfg, w, weight_dtype=a.weights)
 del w
 model.setup_caches(a.batch)
 t2 = time.time()
@@ -45,7 +46,7 @@ if a.e2e:
     secs = res.samples / 24000.0
     print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B end to end: reference-audio prompt (Mimi.encode) + text ids -> frames -> Mimi.decode",
                       "value": B * secs / res.processing_time_seconds, "wall_s": res.processing_time_seconds, "audio_s_per_stream": secs, "batch": B,
-                      "frames": res.token_count, "prompt_frames": 24 + 26 + 24, "dtype": "f32 frame generator, fp32 Mimi.encode, bf16 Mimi.decode",
+                      "frames": res.token_count, "prompt_frames": 24 + 26 + 24, "dtype": ("bf16-weight" if a.weights == "bfloat16" else "f32") + " frame generator, fp32 Mimi.encode, bf16 Mimi.decode",
                       "data": "synthetic (random-init weights, random token ids, noise reference audio, EOS ignored)",
                       "setup_s": {"synth_checkpoint": round(t1 - t0, 1), "load_finalize": round(t2 - t1, 1)}}))
     sys.exit(0)
@@ -73,7 +74,7 @@ for i in range(a.frames):
     codes = model.generate_frame(step_tok, step_msk, temperature=0.9, top_k=50, uniforms=us[3 + i])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - ts) / a.frames
-print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B frame generation (80 ms of audio per frame and stream), fp32", "value": B * 0.08 / dt,
-                  "ms_per_frame": dt * 1e3, "batch": B, "prompt_tokens": a.prompt, "prefill_ms": prefill_ms, "frames_timed": a.frames, "dtype": "f32",
+print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B frame generation (80 ms of audio per frame and stream), " + ("bf16 weights / fp32 arithmetic" if a.weights == "bfloat16" else "fp32"), "value": B * 0.08 / dt,
+                  "ms_per_frame": dt * 1e3, "batch": B, "prompt_tokens": a.prompt, "prefill_ms": prefill_ms, "frames_timed": a.frames, "dtype": "bf16 weights, f32 arithmetic" if a.weights == "bfloat16" else "f32",
                   "data": "synthetic (random-init CSM-1B weights, random prompt, injected uniforms)",
                   "setup_s": {"synth_checkpoint": round(t1 - t0, 1), "load_finalize": round(t2 - t1, 1)}}))
