@@ -156,7 +156,8 @@ def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     from mlx_audio_amd.csm import SesameModel
 
     cfg = P.csm_config()
-    cfg = dict(cfg, text_vocab_size=500, audio_vocab_size=131, audio_num_codebooks=6, max_seq_len=64,
+    # 1100 audio tokens: large enough for the one-wave sampler the real vocabulary (2051) runs on (64 * 16 < V <= 64 * 36)
+    cfg = dict(cfg, text_vocab_size=500, audio_vocab_size=1100, audio_num_codebooks=6, max_seq_len=64,
                backbone=dict(cfg["backbone"], num_layers=2, intermediate=1024), decoder=dict(cfg["decoder"], num_layers=2, intermediate=768))
     w = P.csm_synth_checkpoint(cfg, 2)
     rng = np.random.default_rng(8)
@@ -173,6 +174,16 @@ def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     report("csm/realheads/logits", **e)
     assert e["rel_max"] < 2e-4, e
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    # a single-token frame with top-50 / temperature sampling on injected uniforms: every sampled code equals the oracle's
+    n = cfg["audio_num_codebooks"]
+    t_in = np.zeros((B, 1, n + 1), np.int64)
+    t_in[:, 0, :n] = ref
+    m_in = np.zeros((B, 1, n + 1), np.float32)
+    m_in[:, 0, :n] = 1
+    u = rng.uniform(size=(B, n)).astype(np.float32)
+    ref2 = orc.generate_frame(t_in, m_in, temp=0.9, top_k=50, uniforms=u)
+    got2 = model.generate_frame(torch.tensor(t_in), torch.tensor(m_in), temperature=0.9, top_k=50, uniforms=torch.tensor(u))
+    np.testing.assert_array_equal(got2.cpu().numpy(), ref2)
 
 
 def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
