@@ -153,22 +153,43 @@ __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int
   for (int e = threadIdx.x; e < KV * hd; e += 256) vdst[e] = vsrc[e];
 }
 
-// one workgroup per (query s, head h, item b): scores over the cached keys 0 .. offset+s, softmax, weighted sum of V
+// one workgroup per (query s, head h, item b): scores over the cached keys 0 .. offset+s, softmax, weighted sum of V.
+// Single-token steps are latency-bound, so the dependent chains are kept short: a thread takes a whole key row as independent 16-byte
+// loads (q sits in LDS), and the P.V product splits the keys over G = 512 / hd groups of threads (each thread one float4 of the head
+// dimension), whose partial sums are added in group order through LDS.
 __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, const float* kc,
                                                          const float* vc, int max_pos, float scale, float* out) {
-  extern __shared__ float sc[];  // [max_pos]
+  extern __shared__ __attribute__((aligned(16))) float sc[];  // [max_pos] scores, then [hd] q, then [G][hd] partial outputs
   __shared__ float red[2];
   if (pos_dev) offset += *pos_dev;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = offset + s + 1;
+  const int mp4 = (max_pos + 3) & ~3;
+  float* qs = sc + mp4;        // [hd]
+  float* po = qs + hd;         // [G][hd]
   const float* q = qkv + ((long long)b * S + s) * W + h * hd;
   const float* kb = kc + ((long long)b * max_pos) * KV * hd + kvh * hd;
   const float* vb = vc + ((long long)b * max_pos) * KV * hd + kvh * hd;
+  for (int e = tid; e < hd; e += 128) qs[e] = q[e];
+  __syncthreads();
+  const int hd4 = hd >> 2;
   float mx = -INFINITY;
   for (int j = tid; j < nk; j += 128) {
-    const float* kr = kb + (long long)j * KV * hd;
+    const float4* kr = (const float4*)(kb + (long long)j * KV * hd);
     float d = 0.f;
-    for (int e = 0; e < hd; ++e) d = __builtin_fmaf(q[e], kr[e], d);
+    for (int e0 = 0; e0 < hd4; e0 += 16) {  // hd = 64 or 128: 16 independent loads per trip
+      float4 kv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) kv[t] = kr[e0 + t];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float4 qv = *(const float4*)(qs + 4 * (e0 + t));
+        d = __builtin_fmaf(qv.x, kv[t].x, d);
+        d = __builtin_fmaf(qv.y, kv[t].y, d);
+        d = __builtin_fmaf(qv.z, kv[t].z, d);
+        d = __builtin_fmaf(qv.w, kv[t].w, d);
+      }
+    }
     d *= scale;
     sc[j] = d;
     mx = fmaxf(mx, d);
@@ -188,12 +209,27 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   if ((tid & 63) == 0) red[tid >> 6] = sum;
   __syncthreads();
   const float inv = 1.0f / (red[0] + red[1]);
+  const int G = 128 / hd4, e4 = tid % hd4, g = tid / hd4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = g; j < nk; j += G) {
+    const float p = sc[j];
+    const float4 v = *(const float4*)(vb + (long long)j * KV * hd + 4 * e4);
+    acc.x = __builtin_fmaf(p, v.x, acc.x);
+    acc.y = __builtin_fmaf(p, v.y, acc.y);
+    acc.z = __builtin_fmaf(p, v.z, acc.z);
+    acc.w = __builtin_fmaf(p, v.w, acc.w);
+  }
+  *(float4*)(po + g * hd + 4 * e4) = acc;
+  __syncthreads();
   for (int e = tid; e < hd; e += 128) {
-    float acc = 0.f;
-    for (int j = 0; j < nk; ++j) acc = __builtin_fmaf(sc[j], vb[(long long)j * KV * hd + e], acc);
-    out[((long long)b * S + s) * H * hd + h * hd + e] = acc * inv;
+    float a = 0.f;
+    for (int gg = 0; gg < G; ++gg) a += po[gg * hd + e];  // group order
+    out[((long long)b * S + s) * H * hd + h * hd + e] = a * inv;
   }
 }
+
+// dynamic LDS of attn_cache_kernel: scores (padded to 4) + q + G partial outputs of hd floats, G = 512 / hd
+static size_t attn_lds_bytes(int max_pos, int hd) { return ((size_t)((max_pos + 3) & ~3) + hd + (size_t)(512 / hd) * hd) * 4; }
 
 __global__ void advance_pos_kernel(int* pos, int by) { *pos += by; }
 
@@ -708,7 +744,7 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
     if (!r.dry) {
       hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
       KK_CHECK_LAUNCH();
-      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), (size_t)st.max_pos * 4, r.st, qkv, S, H, KV, hd, st.pos_dev, st.pos_dev ? 0 : offset, kc,
+      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev, st.pos_dev ? 0 : offset, kc,
                          vc, st.max_pos, 1.0f / sqrtf((float)hd), att);
       KK_CHECK_LAUNCH();
     }
@@ -797,7 +833,8 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
 
 int check_llama(const kk_llama_args& a) {
   if (a.num_layers < 1 || a.num_heads < 1 || a.num_kv_heads < 1 || a.num_heads % a.num_kv_heads != 0) return kk_fail("kk_csm_create: bad head counts");
-  if (a.head_dim < 2 || (a.head_dim & 1) || a.hidden < 1 || a.intermediate < 1) return kk_fail("kk_csm_create: bad sizes");
+  if (a.hidden < 1 || a.intermediate < 1) return kk_fail("kk_csm_create: bad sizes");
+  if (a.head_dim != 64 && a.head_dim != 128) return kk_fail("kk_csm_create: head_dim must be 64 or 128 (llama-1B / llama-100M, sesame.py:225-273)");
   return 0;
 }
 
