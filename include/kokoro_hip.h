@@ -272,6 +272,9 @@ int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, const int32_t* 
  * hipGraphLaunch (the backbone position is a device counter, so the captured step is position-independent); results are unchanged */
 int kk_csm_set_graph_mode(kk_csm* m, int on);
 int kk_csm_debug_logits(kk_csm* m, void* stream, int B, float* dst); /* logits of the last frame, [n_cb][B][audio_vocab] */
+/* the sampler of generate_frame on its own (mlx_lm make_sampler(temp, top_k), sesame.py:335-336,719): logits [B][V] -> codes [B];
+ * uniforms [B] or NULL (argmax).  Radix select of the top_k set + one-wave sort; V <= 8192. */
+int kk_op_csm_sample(void* stream, int B, int V, const float* logits, float temperature, int top_k, const float* uniforms, int32_t* codes_out);
 
 #ifdef __cplusplus
 }

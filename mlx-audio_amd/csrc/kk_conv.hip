@@ -18,7 +18,9 @@ constexpr int BM = 128, BN = 64, BK = 16;
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-template <typename TI, typename TO>
+// ELU: elu(x, 1) on the input while it is staged (Mimi SEANet) -- a template parameter: as a run-time select the exp() was evaluated
+// for every staged element of every conv (+16 % on the fp32 Kokoro forward)
+template <typename TI, typename TO, bool ELU>
 __global__ __launch_bounds__(256) void conv_generic_kernel(KKConvArgs a) {
   __shared__ __attribute__((aligned(16))) float As[BK][BM + 4];
   __shared__ __attribute__((aligned(16))) float Bs[BK][BN + 4];
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(KKConvArgs a) {
         for (int i = 0; i < 8; ++i) {
           const int c = c0 + ak0 + i;
           float v = (rv && c < a.Cin) ? kk_ld(xr + c) : 0.f;
-          av[i] = a.in_act == KK_ACT_ELU ? (v > 0.f ? v : expf(v) - 1.0f)  // nn.elu: where(x > 0, x, exp(x) - 1)
-                                          : (v > 0.f ? v : v * a.in_slope);
+          av[i] = ELU ? (v > 0.f ? v : expf(v) - 1.0f)  // nn.elu: where(x > 0, x, exp(x) - 1)
+                      : (v > 0.f ? v : v * a.in_slope);
         }
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 + bk < a.Cin) bv = *(const float4*)(wt + (long long)(c0 + bk) * a.ldw + co0 + bn);
@@ -131,16 +133,19 @@ int kk_launch_conv_generic(const KKConvArgs& a, int B, int in_dtype, int out_dty
   if (a.Q <= 0 || B <= 0) return 0;
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
   dim3 grid(kk_cdiv(a.Q, BM), kk_cdiv(a.Cout, BN), B * nphase);
-  if (in_dtype == KK_F32 && out_dtype == KK_F32)
-    hipLaunchKernelGGL((conv_generic_kernel<float, float>), grid, dim3(256), 0, st, a);
-  else if (in_dtype == KK_BF16 && out_dtype == KK_BF16)
-    hipLaunchKernelGGL((conv_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, a);
-  else if (in_dtype == KK_BF16 && out_dtype == KK_F32)
-    hipLaunchKernelGGL((conv_generic_kernel<bf16_t, float>), grid, dim3(256), 0, st, a);
-  else if (in_dtype == KK_F32 && out_dtype == KK_BF16)
-    hipLaunchKernelGGL((conv_generic_kernel<float, bf16_t>), grid, dim3(256), 0, st, a);
+  const bool elu = a.in_act == KK_ACT_ELU;
+#define KK_GO(TI, TO)                                                                                      \
+  do {                                                                                                     \
+    if (elu) hipLaunchKernelGGL((conv_generic_kernel<TI, TO, true>), grid, dim3(256), 0, st, a);           \
+    else hipLaunchKernelGGL((conv_generic_kernel<TI, TO, false>), grid, dim3(256), 0, st, a);              \
+  } while (0)
+  if (in_dtype == KK_F32 && out_dtype == KK_F32) KK_GO(float, float);
+  else if (in_dtype == KK_BF16 && out_dtype == KK_BF16) KK_GO(bf16_t, bf16_t);
+  else if (in_dtype == KK_BF16 && out_dtype == KK_F32) KK_GO(bf16_t, float);
+  else if (in_dtype == KK_F32 && out_dtype == KK_BF16) KK_GO(float, bf16_t);
   else
     return kk_fail("conv_generic: bad dtype");
+#undef KK_GO
   KK_CHECK_LAUNCH();
   return 0;
 }

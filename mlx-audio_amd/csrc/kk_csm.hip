@@ -245,23 +245,16 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* gu, int I, lon
 
 // one workgroup per item: argmax (temp == 0 or no uniforms) or inverse CDF over the top_k logits in descending order
 // (ties: lower index first) of softmax(logit / temp) with the injected uniform u[b].
-// Selection: every thread keeps its V / 256 logits and their running maximum in registers; a round is one wave-shuffle argmax, one
+// Round-based selection (the fallback of sample_select_kernel below): every thread keeps its V / 256 logits and their running maximum in registers; a round is one wave-shuffle argmax, one
 // LDS exchange between the four waves (double-buffered: one barrier per round) and a re-scan by the single thread that owned the
 // winner -- ~0.3 us per round instead of a scan of all V logits from LDS plus an eight-level LDS tree (90 -> ~15 us for top-50).
 template <int NPER>
-__global__ __launch_bounds__(256) void sample_kernel(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out,
-                                                     int ostride) {
+__device__ void sample_rounds(float (&v)[NPER], int V, float temp, int top_k, const float* u, int ustride, int* out, int ostride) {
   __shared__ float wv[2][4];
   __shared__ int wi[2][4];
   __shared__ float topv[64];
   __shared__ int topi[64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float v[NPER];
-#pragma unroll
-  for (int i = 0; i < NPER; ++i) {
-    const int j = tid + 256 * i;
-    v[i] = j < V ? logits[(long long)b * V + j] : -INFINITY;
-  }
   float bv = -INFINITY;
   int bi = 0x7fffffff;
 #pragma unroll
@@ -318,55 +311,111 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int V,
     out[(long long)b * ostride] = pick;
   }
 }
-// the same selection by ONE wave per item (V <= 64 * NPER): no barrier and no LDS exchange per round, just the shuffle argmax and the
-// owner lane's re-scan -- the 256-thread form spends most of a round in its barrier
+// Top-k by radix SELECT instead of k rounds of arg-max (rounds are serial: 50 x ~1.3 us however they are organised -- a 256-thread
+// barrier per round or a 12-shuffle chain per round in one wave).  Logits become order-preserving 32-bit keys in registers; four 8-bit
+// histogram passes (LDS atomics, one wave scans the 256 bins from the top) find the key of the k-th largest logit; every logit >= that key
+// is a candidate (k of them plus ties of the k-th); ONE wave sorts the <= 64 candidates (bitonic, value descending, index ascending on
+// ties: the oracle's order) and the softmax / inverse-CDF tail is the old one.  More than 64 candidates (a wall of exactly equal logits)
+// falls back to the round-based kernel.  Same picks as before, bit for bit.
+__device__ __forceinline__ unsigned sk_key(float f) {
+  const unsigned bits = __float_as_uint(f);
+  return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+__device__ __forceinline__ float sk_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 template <int NPER>
-__global__ __launch_bounds__(64) void sample_wave_kernel(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out,
-                                                         int ostride) {
-  __shared__ float topv[64];
+__global__ __launch_bounds__(256) void sample_select_kernel(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out,
+                                                            int ostride) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_krem, ccount;
+  __shared__ unsigned ckey[64];
+  __shared__ int cidx[64];
+  __shared__ float topv[64], ev[64];
   __shared__ int topi[64];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  float v[NPER];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned key[NPER];
 #pragma unroll
   for (int i = 0; i < NPER; ++i) {
-    const int j = lane + 64 * i;
-    v[i] = j < V ? logits[(long long)b * V + j] : -INFINITY;
+    const int j = tid + 256 * i;
+    key[i] = j < V ? sk_key(logits[(long long)b * V + j]) : 0u;
   }
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-#pragma unroll
-  for (int i = 0; i < NPER; ++i)
-    if (v[i] > bv) { bv = v[i]; bi = lane + 64 * i; }
   const bool greedy = u == nullptr || temp == 0.f;
   const int k = greedy ? 1 : (top_k < 64 ? (top_k < V ? top_k : V) : 64);
-  for (int r = 0; r < k; ++r) {
-    float gv = bv;
-    int gi = bi;
+  unsigned prefix = 0u, mask = 0u, krem = (unsigned)k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0u;
+    __syncthreads();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(gv, o);
-      const int oi = __shfl_xor(gi, o);
-      if (ov > gv || (ov == gv && oi < gi)) { gv = ov; gi = oi; }
-    }
-    if (lane == 0) { topv[r] = gv; topi[r] = gi; }
-    if (gi != 0x7fffffff && (gi & 63) == lane) {
-      bv = -INFINITY;
-      bi = 0x7fffffff;
+    for (int i = 0; i < NPER; ++i)
+      if (tid + 256 * i < V && (key[i] & mask) == prefix) atomicAdd(&hist[(key[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (wave == 0) {  // lane l owns bins 255 - 4l .. 252 - 4l: ascending lanes walk the digits from the top
+      const unsigned c0 = hist[255 - 4 * lane], c1 = hist[254 - 4 * lane], c2 = hist[253 - 4 * lane], c3 = hist[252 - 4 * lane];
+      const unsigned sum = c0 + c1 + c2 + c3;
+      unsigned inc = sum;
 #pragma unroll
-      for (int i = 0; i < NPER; ++i) {
-        if (i == (gi >> 6)) v[i] = -INFINITY;
-        if (v[i] > bv) { bv = v[i]; bi = lane + 64 * i; }
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      const unsigned exc = inc - sum;
+      if (exc < krem && krem <= inc) {  // exactly one lane: the digit that holds the krem-th largest of the surviving keys
+        const unsigned r = krem - exc;
+        unsigned bin, above;
+        if (r <= c0) { bin = 255 - 4 * lane; above = exc; }
+        else if (r <= c0 + c1) { bin = 254 - 4 * lane; above = exc + c0; }
+        else if (r <= c0 + c1 + c2) { bin = 253 - 4 * lane; above = exc + c0 + c1; }
+        else { bin = 252 - 4 * lane; above = exc + c0 + c1 + c2; }
+        s_prefix = prefix | (bin << shift);
+        s_krem = krem - above;
       }
     }
+    __syncthreads();
+    prefix = s_prefix;
+    krem = s_krem;
+    mask |= 255u << shift;
   }
+  if (tid == 0) ccount = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NPER; ++i)
+    if (tid + 256 * i < V && key[i] >= prefix) {
+      const unsigned p = atomicAdd(&ccount, 1u);
+      if (p < 64u) { ckey[p] = key[i]; cidx[p] = tid + 256 * i; }
+    }
+  __syncthreads();
+  const unsigned nc = ccount;
+  if (nc > 64u) {  // block-uniform: a wall of equal logits -- the round-based selection handles any input
+    float v[NPER];
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) v[i] = tid + 256 * i < V ? sk_unkey(key[i]) : -INFINITY;
+    sample_rounds<NPER>(v, V, temp, top_k, u, ustride, out, ostride);
+    return;
+  }
+  if (wave != 0) return;
+  unsigned kk = lane < (int)nc ? ckey[lane] : 0u;
+  int ii = lane < (int)nc ? cidx[lane] : 0x7fffffff;
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const unsigned ok = __shfl_xor(kk, stride);
+      const int oi = __shfl_xor(ii, stride);
+      const bool other_first = ok > kk || (ok == kk && oi < ii);  // `other` precedes `mine` in the wanted order
+      const bool want_first = ((lane & stride) == 0) == ((lane & size) == 0 || size == 64);  // this lane keeps the earlier element
+      if (other_first == want_first) { kk = ok; ii = oi; }
+    }
+  if (lane < k) { topv[lane] = sk_unkey(kk); topi[lane] = ii; }
+  __builtin_amdgcn_wave_barrier();
+  if (!greedy && lane < k) ev[lane] = expf(topv[lane] / temp - topv[0] / temp);
+  __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     int pick = topi[0];
     if (!greedy) {
       float c[64];
-      const float z0 = topv[0] / temp;
       float run = 0.f;
       for (int r = 0; r < k; ++r) {
-        run += expf(topv[r] / temp - z0);
+        run += ev[r];
         c[r] = run;
       }
       const float target = u[(long long)b * ustride] * run;
@@ -377,15 +426,11 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(const float* logits, in
     out[(long long)b * ostride] = pick;
   }
 }
+
 int launch_sample(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out, int ostride, int B, hipStream_t st) {
-  if (V <= 64 * 36 && V > 64 * 16) {
-    hipLaunchKernelGGL(sample_wave_kernel<36>, dim3(B), dim3(64), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
-    KK_CHECK_LAUNCH();
-    return 0;
-  }
-  if (V <= 256 * 4) hipLaunchKernelGGL(sample_kernel<4>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
-  else if (V <= 256 * 9) hipLaunchKernelGGL(sample_kernel<9>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
-  else if (V <= 256 * 32) hipLaunchKernelGGL(sample_kernel<32>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
+  if (V <= 256 * 4) hipLaunchKernelGGL(sample_select_kernel<4>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
+  else if (V <= 256 * 9) hipLaunchKernelGGL(sample_select_kernel<9>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
+  else if (V <= 256 * 32) hipLaunchKernelGGL(sample_select_kernel<32>, dim3(B), dim3(256), 0, st, logits, V, temp, top_k, u, ustride, out, ostride);
   else return kk_fail("kk_csm: audio vocabulary larger than 8192 entries");
   KK_CHECK_LAUNCH();
   return 0;
@@ -839,6 +884,12 @@ int check_llama(const kk_llama_args& a) {
 }
 
 }  // namespace
+
+// make_sampler(temp, top_k) on its own (tests): logits [B][V] fp32 -> codes [B] int32, uniforms [B] (NULL or temp == 0: argmax)
+extern "C" int kk_op_csm_sample(void* stream, int B, int V, const float* logits, float temperature, int top_k, const float* uniforms, int32_t* codes_out) {
+  if (!logits || !codes_out || B < 1 || V < 1) return kk_fail("kk_op_csm_sample: bad argument");
+  return launch_sample(logits, V, temperature, top_k, uniforms, 1, codes_out, 1, B, (hipStream_t)stream);
+}
 
 extern "C" int kk_csm_create(const kk_csm_config* cfg, kk_csm** out) {
   if (!cfg || !out) return kk_fail("kk_csm_create: null argument");

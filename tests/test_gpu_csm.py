@@ -260,3 +260,31 @@ def test_csm_golden_fixture_without_oracle():
         t_in[:, 0, :n] = c
         m_in = np.zeros((B, 1, n + 1), np.float32)
         m_in[:, 0, :n] = 1
+
+
+@pytest.mark.parametrize("V", [67, 1100, 2051, 4000])
+def test_csm_sampler_matches_oracle_incl_tie_walls(V):
+    """kk_op_csm_sample against oracle sample(): random logits, quantised logits (many exact ties inside and at the edge of the top-k
+    set), an all-equal row (more than 64 candidates: the round-based fallback), -inf entries; greedy and top-k / temperature."""
+    import ctypes as CT
+
+    from mlx_audio_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(V)
+    rows = [rng.standard_normal(V) * 3, np.round(rng.standard_normal(V) * 2) / 2, np.zeros(V), np.round(rng.standard_normal(V)),
+            np.where(rng.uniform(size=V) < 0.5, -np.inf, rng.standard_normal(V)), -np.abs(rng.standard_normal(V)) * 50]
+    lg = np.stack(rows).astype(np.float32)
+    B = lg.shape[0]
+    d = torch.tensor(lg, device="cuda")
+    for temp, top_k in ((0.0, 50), (0.9, 50), (0.7, 5), (1.3, 64)):
+        for trial in range(3):
+            u = rng.uniform(size=B).astype(np.float32)
+            ref = C.sample(torch.tensor(lg), temp, min(top_k, V), u if temp else None)
+            ud = torch.tensor(u, device="cuda")
+            out = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+            rc = lib.kk_op_csm_sample(CT.c_void_p(torch.cuda.current_stream().cuda_stream), B, V, CT.c_void_p(d.data_ptr()), temp, top_k,
+                                      CT.c_void_p(ud.data_ptr()) if temp else None, CT.c_void_p(out.data_ptr()))
+            assert rc == 0, lib.kk_last_error()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"temp {temp} top_k {top_k}")
