@@ -146,7 +146,9 @@ class Model:
         if voice is None:
             voice = "af_heart"
         start = time.time()
-        for segment_idx, (graphemes, phonemes, audio) in enumerate(pipeline(text, voice=voice, speed=speed, split_pattern=split_pattern)):
+        # batch_size (an addition): chunks of one request synthesised as padded batches (KokoroPipeline.plan_batches); 1 = the reference's chunk by chunk
+        for segment_idx, (graphemes, phonemes, audio) in enumerate(pipeline(text, voice=voice, speed=speed, split_pattern=split_pattern,
+                                                                            batch_size=int(kwargs.get("batch_size", 1)))):
             torch.cuda.synchronize()
             now = time.time()
             seg_t, start = now - start, now

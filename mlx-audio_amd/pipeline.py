@@ -226,14 +226,8 @@ class KokoroPipeline:
         def __len__(self):
             return 3
 
-    def __call__(self, text: Union[str, List[str]], voice: Optional[str] = None, speed: Number = 1,
-                 split_pattern: Optional[str] = r"\n+"):
-        if voice is None:
-            raise ValueError('Specify a voice: en_us_pipeline(text="Hello world!", voice="af_heart")')
-        if self.g2p is None:
-            raise ImportError("text input needs a G2P: `pip install misaki[en]` (what the reference uses) or pass g2p=...; "
-                              "phoneme strings work through generate_from_tokens()")
-        pack = self.load_voice(voice) if self.model else None
+    def _chunks(self, text: Union[str, List[str]], split_pattern: Optional[str]):
+        """The reference's chunking of pipeline.py:371-436 as a flat stream of (text_index, graphemes, phonemes, tokens | None)."""
         if isinstance(text, str):
             text = re.split(split_pattern, text.strip()) if split_pattern else [text]
         for gi, graphemes in enumerate(text):
@@ -244,21 +238,59 @@ class KokoroPipeline:
                 for gs, ps, tks in self.en_tokenize(tokens):
                     if not ps:
                         continue
-                    if len(ps) > 510:
-                        ps = ps[:510]
-                    output = KokoroPipeline.infer(self.model, ps, pack, speed) if self.model else None
-                    if output is not None and output.pred_dur is not None:
-                        KokoroPipeline.join_timestamps(tks, output.pred_dur)
-                    yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output, text_index=gi)
+                    yield gi, gs, ps[:510], tks
             else:
                 for chunk in _sentence_chunks(graphemes, 400):  # pipeline.py:408-436
                     ps, _ = self.g2p(chunk)
                     if not ps:
                         continue
-                    if len(ps) > 510:
-                        ps = ps[:510]
-                    output = KokoroPipeline.infer(self.model, ps, pack, speed) if self.model else None
-                    yield self.Result(graphemes=chunk, phonemes=ps, output=output, text_index=gi)
+                    yield gi, chunk, ps[:510], None
+
+    @staticmethod
+    def plan_batches(lengths: List[int], batch_size: int, max_pad: float = 0.25) -> List[List[int]]:
+        """Batch scheduler of the chunk stream: chunks sorted by phoneme count and cut into batches of at most `batch_size` whose shortest
+        member is no more than `max_pad` shorter than the longest (padded tokens and frames are wasted work on the GPU; a batch's cost is
+        set by its longest utterance).  Returns lists of chunk indices; every index appears exactly once."""
+        order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+        batches, cur = [], []
+        for i in order:
+            if cur and (len(cur) >= batch_size or lengths[i] < (1.0 - max_pad) * lengths[cur[0]]):
+                batches.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
+            batches.append(cur)
+        return batches
+
+    def __call__(self, text: Union[str, List[str]], voice: Optional[str] = None, speed: Number = 1,
+                 split_pattern: Optional[str] = r"\n+", batch_size: int = 1):
+        """pipeline.py:358-436.  batch_size > 1 (an addition: the reference synthesises chunk by chunk, batch 1): all chunks of the request are
+        phonemised first, grouped by `plan_batches` and synthesised as padded batches (`Model.batch_call`: every utterance's result is bit-identical
+        to its batch-1 result up to the noise seed); results are still yielded in text order."""
+        if voice is None:
+            raise ValueError('Specify a voice: en_us_pipeline(text="Hello world!", voice="af_heart")')
+        if self.g2p is None:
+            raise ImportError("text input needs a G2P: `pip install misaki[en]` (what the reference uses) or pass g2p=...; "
+                              "phoneme strings work through generate_from_tokens()")
+        pack = self.load_voice(voice) if self.model else None
+        if batch_size <= 1 or not self.model:
+            for gi, gs, ps, tks in self._chunks(text, split_pattern):
+                output = KokoroPipeline.infer(self.model, ps, pack, speed) if self.model else None
+                if tks is not None and output is not None and output.pred_dur is not None:
+                    KokoroPipeline.join_timestamps(tks, output.pred_dur)
+                yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output, text_index=gi)
+            return
+        chunks = list(self._chunks(text, split_pattern))
+        outputs = [None] * len(chunks)
+        for idx in KokoroPipeline.plan_batches([len(c[2]) for c in chunks], batch_size):
+            ps_list = [chunks[i][2] for i in idx]
+            rows = np.stack([np.asarray(pack[len(ps) - 1], np.float32).reshape(256) for ps in ps_list])  # pipeline.py:236, one row per chunk
+            for i, o in zip(idx, self.model.batch_call(ps_list, rows, speed)):
+                outputs[i] = o
+        for (gi, gs, ps, tks), output in zip(chunks, outputs):
+            if tks is not None and output.pred_dur is not None:
+                KokoroPipeline.join_timestamps(tks, output.pred_dur)
+            yield self.Result(graphemes=gs, phonemes=ps, tokens=tks, output=output, text_index=gi)
 
 
 def _sentence_chunks(graphemes: str, chunk_size: int) -> List[str]:

@@ -561,3 +561,26 @@ def test_python_surface_load_model_pipeline_both_layouts(tmp_path):
         np.testing.assert_array_equal(o2.pred_dur.cpu().numpy(), outs[-1][1])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+def test_pipeline_batch_scheduler_matches_chunk_by_chunk(tmp_path):
+    """KokoroPipeline(..., batch_size=N): the request's chunks run as padded batches planned by length; every chunk's durations -- and so
+    its audio length and timestamps -- equal the chunk-by-chunk (batch 1, reference) run's, and the results come back in text order."""
+    from mlx_audio_amd.kokoro import Model, ModelConfig
+    from mlx_audio_amd.pipeline import KokoroPipeline
+
+    cfg = P.tiny_config()
+    cfg["vocab"] = P.load_vocab()
+    model = Model(ModelConfig.from_dict(dict(cfg, model_type="kokoro")), weights=P.synth_checkpoint(cfg, 0))
+    rows = np.load(os.path.join(GOLDEN, "af_heart_rows.npz"))["rows"]
+    np.save(tmp_path / "voice.npy", np.stack([rows[i % rows.shape[0]] for i in range(510)])[:, None, :])
+    letters = [c for c in "abdefhijklmnopstuvwz" if c in cfg["vocab"]]
+    rng = np.random.default_rng(3)
+    lines = ["".join(rng.choice(letters, n)) for n in (40, 6, 38, 90, 7, 41, 5, 88)]
+    pipe = KokoroPipeline(lang_code="e", model=model, repo_id="local", g2p=lambda t: (t, None))  # identity G2P: the lines ARE phoneme strings
+    seq = list(pipe("\n".join(lines), voice=str(tmp_path / "voice.npy")))
+    bat = list(pipe("\n".join(lines), voice=str(tmp_path / "voice.npy"), batch_size=4))
+    assert [r.phonemes for r in bat] == lines == [r.phonemes for r in seq]
+    for a, b in zip(seq, bat):
+        np.testing.assert_array_equal(a.pred_dur.cpu().numpy(), b.pred_dur.cpu().numpy())
+        assert a.audio.shape == b.audio.shape and torch.isfinite(b.audio).all()

@@ -179,3 +179,39 @@ def test_mlx_affine_quantisation_round_trip():
     out = dequantize_checkpoint(ck, 64, 8)
     assert set(out) == {"a.weight", "b.weight", "c.bias"} and out["a.weight"].shape == (1, 64) and out["a.weight"].dtype == np.float32
     np.testing.assert_allclose(out["a.weight"][0], np.arange(64), atol=0.5 * float(scales[0, 0]) + 1e-5)
+
+
+def test_batch_scheduler_plans_and_keeps_text_order():
+    """plan_batches: every chunk once, batches bounded in size and in padding waste, longest first; the batched __call__ yields the
+    chunks in text order with the outputs of the batch they ran in (fake model: no GPU)."""
+    rng = np.random.default_rng(0)
+    lens = rng.integers(5, 500, 57).tolist()
+    plan = KokoroPipeline.plan_batches(lens, 8, 0.25)
+    assert sorted(i for b in plan for i in b) == list(range(57))
+    assert all(1 <= len(b) <= 8 for b in plan)
+    assert all(min(lens[i] for i in b) >= 0.75 * max(lens[i] for i in b) for b in plan)
+    assert [max(lens[i] for i in b) for b in plan] == sorted((max(lens[i] for i in b) for b in plan), reverse=True)
+    assert KokoroPipeline.plan_batches([], 8) == [] and KokoroPipeline.plan_batches([3], 8) == [[0]]
+
+    calls = []
+
+    class FakeModel:
+        def batch_call(self, phonemes, ref_s, speed=1, seed=None):
+            calls.append(list(phonemes))
+            assert ref_s.shape == (len(phonemes), 256)
+            # the style row of a chunk is pack[len(ps) - 1] (pipeline.py:236): the fake pack stores its own row index
+            assert [int(r[0]) for r in ref_s] == [len(p) - 1 for p in phonemes]
+            return [SimpleNamespace(audio=np.full((1, 600 * len(p)), float(len(p)), np.float32), pred_dur=None) for p in phonemes]
+
+        def __call__(self, ps, ref_s, speed=1, return_output=False):
+            return self.batch_call([ps], np.asarray(ref_s).reshape(1, 256), speed)[0]
+
+    words = ["a" * n for n in (30, 7, 31, 8, 29, 300)]
+    p = KokoroPipeline(lang_code="e", model=FakeModel(), repo_id="m", g2p=lambda t: (t, None))  # identity G2P, non-English branch
+    p.voices["v"] = np.repeat(np.arange(510, dtype=np.float32)[:, None, None], 256, axis=2)
+    res = list(p("\n".join(words), voice="v", batch_size=4))
+    assert [r.phonemes for r in res] == words and [r.text_index for r in res] == list(range(6))
+    assert [float(r.audio[0, 0]) for r in res] == [float(len(w)) for w in words]
+    assert sorted(map(sorted, calls)) == sorted(map(sorted, [["a" * 300], ["a" * 31, "a" * 30, "a" * 29], ["a" * 8, "a" * 7]]))
+    calls.clear()
+    assert [r.phonemes for r in p("\n".join(words), voice="v")] == words and all(len(c) == 1 for c in calls)  # default: chunk by chunk
