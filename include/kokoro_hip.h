@@ -228,6 +228,19 @@ int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int32_t* codes
 int kk_mimi_encode_frames(const kk_mimi* m, int N); /* ceil chain over the ratios and the resampler: 120000 -> 63 */
 size_t kk_mimi_encode_workspace_bytes(kk_mimi* m, int B, int N);
 int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out);
+/* Streaming decode: Mimi.decode_step / MimiStreamingDecoder (mimi.py:163-168,264-306; conv.py:265-351; seanet.py:219-223,277-283).
+ * A stream owns its state in device memory: the previous quantised frame (the 2x resampler looks back one frame), the KV caches of the
+ * decoder transformer (last 250 cached positions + the step's own, no mask: transformer.py:79-104) and a window of the last 16 transformer
+ * outputs over which the causal SEANet decoder is re-run each step (it equals the reference's per-layer conv state exactly: a causal
+ * convolution's streaming output is its offline output at those positions).  codes [B][nq] int32 (one frame) -> pcm [B][samples_per_frame].
+ * fp32 kernels; B is fixed between resets; at most max_frames steps per reset. */
+typedef struct kk_mimi_stream kk_mimi_stream;
+int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out);
+void kk_mimi_stream_destroy(kk_mimi_stream* s);
+int kk_mimi_stream_reset(kk_mimi_stream* s); /* MimiStreamingDecoder.reset */
+int kk_mimi_stream_frames(const kk_mimi_stream* s);
+size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B);
+int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);
 /* intermediates of the last decode / encode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3" (decode), "seanet", "transformer", "downsampled" (encode); [B][rows][channels] fp32 */
 int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels);
 int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);

@@ -97,6 +97,12 @@ SIGNATURES = {
     "kk_mimi_samples_per_frame": (C.c_int64, [_vp]),
     "kk_mimi_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_mimi_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "kk_mimi_stream_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "kk_mimi_stream_destroy": (None, [_vp]),
+    "kk_mimi_stream_reset": (_i, [_vp]),
+    "kk_mimi_stream_frames": (_i, [_vp]),
+    "kk_mimi_stream_workspace_bytes": (_sz, [_vp, _i]),
+    "kk_mimi_decode_step": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_encode_frames": (_i, [_vp, _i]),
     "kk_mimi_encode_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_mimi_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -157,19 +157,22 @@ __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int
 // Single-token steps are latency-bound, so the dependent chains are kept short: a thread takes a whole key row as independent 16-byte
 // loads (q sits in LDS), and the P.V product splits the keys over G = 512 / hd groups of threads (each thread one float4 of the head
 // dimension), whose partial sums are added in group order through LDS.
+// `causal`: 1 = query s sees keys 0 .. offset+s (index_causal_mask, sesame.py:41-48); 0 = every query of the block sees all offset+S
+// keys (Mimi's streaming transformer passes no mask, transformer.py:79-104).  `ctx` >= 0: only the last ctx CACHED keys (+ the block).
 __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, const float* kc,
-                                                         const float* vc, int max_pos, float scale, float* out) {
+                                                         const float* vc, int max_pos, float scale, float* out, int causal, int ctx) {
   extern __shared__ __attribute__((aligned(16))) float sc[];  // [max_pos] scores, then [hd] q, then [G][hd] partial outputs
   __shared__ float red[2];
   if (pos_dev) offset += *pos_dev;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = offset + s + 1;
+  const int klo = ctx >= 0 && offset > ctx ? offset - ctx : 0;
+  const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = (causal ? offset + s + 1 : offset + S) - klo;
   const int mp4 = (max_pos + 3) & ~3;
   float* qs = sc + mp4;        // [hd]
   float* po = qs + hd;         // [G][hd]
   const float* q = qkv + ((long long)b * S + s) * W + h * hd;
-  const float* kb = kc + ((long long)b * max_pos) * KV * hd + kvh * hd;
-  const float* vb = vc + ((long long)b * max_pos) * KV * hd + kvh * hd;
+  const float* kb = kc + ((long long)b * max_pos + klo) * KV * hd + kvh * hd;
+  const float* vb = vc + ((long long)b * max_pos + klo) * KV * hd + kvh * hd;
   for (int e = tid; e < hd; e += 128) qs[e] = q[e];
   __syncthreads();
   const int hd4 = hd >> 2;
@@ -790,7 +793,7 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
       hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
       KK_CHECK_LAUNCH();
       hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev, st.pos_dev ? 0 : offset, kc,
-                         vc, st.max_pos, 1.0f / sqrtf((float)hd), att);
+                         vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1);
       KK_CHECK_LAUNCH();
     }
     // h += o(att); x = RMSNorm(h) (post_attention_layernorm)
@@ -884,6 +887,23 @@ int check_llama(const kk_llama_args& a) {
 }
 
 }  // namespace
+
+// the cache kernels on their own (Mimi's streaming transformer, kk_mimi.hip): interleaved-pair RoPE from a [max_pos][hd/2][2] cos|sin
+// table on q (in place) and k, k / v appended to the caches at `offset`; attention of the S new queries over the cache
+int kk_launch_rope_append(float* qkv, int S, int H, int KV, int hd, const float* rope, int offset, float* kc, float* vc, int max_pos, int B, hipStream_t st) {
+  if (hd != 64 && hd != 128) return kk_fail("rope_append: head_dim must be 64 or 128");
+  hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, st, qkv, S, H, KV, hd, rope, (const int*)nullptr, offset, kc, vc, max_pos);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+int kk_launch_attn_cache(const float* qkv, int S, int H, int KV, int hd, int offset, const float* kc, const float* vc, int max_pos, float scale, float* out,
+                         int causal, int ctx, int B, hipStream_t st) {
+  if (hd != 64 && hd != 128) return kk_fail("attn_cache: head_dim must be 64 or 128");
+  hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), attn_lds_bytes(max_pos, hd), st, qkv, S, H, KV, hd, (const int*)nullptr, offset, kc, vc, max_pos,
+                     scale, out, causal, ctx);
+  KK_CHECK_LAUNCH();
+  return 0;
+}
 
 // make_sampler(temp, top_k) on its own (tests): logits [B][V] fp32 -> codes [B] int32, uniforms [B] (NULL or temp == 0: argmax)
 extern "C" int kk_op_csm_sample(void* stream, int B, int V, const float* logits, float temperature, int top_k, const float* uniforms, int32_t* codes_out) {

@@ -245,3 +245,8 @@ bool kk_mxfp8_eligible(int K, int N);
 int kk_mxfp8_pack_weight_host(const float* w, int N, int K, int group, unsigned char* q, unsigned char* s);
 int kk_launch_mxfp8_quant_rows(const void* x_bf16, int ldx, int M, int K, void* aq, void* as, hipStream_t st);
 int kk_launch_linear_mxfp8(const KKFp8Args& a, hipStream_t st);
+
+// ---- KV-cache kernels of kk_csm.hip, shared with Mimi's streaming transformer (kk_mimi.hip)
+int kk_launch_rope_append(float* qkv, int S, int H, int KV, int hd, const float* rope, int offset, float* kc, float* vc, int max_pos, int B, hipStream_t st);
+int kk_launch_attn_cache(const float* qkv, int S, int H, int KV, int hd, int offset, const float* kc, const float* vc, int max_pos, float scale, float* out,
+                         int causal, int ctx, int B, hipStream_t st);

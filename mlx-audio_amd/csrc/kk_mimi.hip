@@ -16,6 +16,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -477,40 +478,12 @@ int run_transformer(Run& r, const std::vector<MimiLayer>& layers, Act& x, Act& n
   return 0;
 }
 
-int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
+// SEANet decoder (seanet.py:228-283) on x [B][T][dim] -> pcm [B][T * prod(ratios)]
+int run_seanet(Run& r, const Act& x, float* pcm, const char* who) {
   kk_mimi* m = r.m;
   const kk_mimi_config& c = m->cfg;
-  const int B = r.B, D = c.dim, Q = c.qdim, T = Nf * c.upsample_stride;
-  const bool bf = m->adt == KK_BF16;
-  // ---- split RVQ decode
-  Act q1 = r.act(Nf, Q), q2 = r.act(Nf, Q), x0 = r.act(Nf, D), xu = r.act(T, D), x = r.act(T, D);
-  Act n = r.act(T, D), qkv = r.act(T, 3 * D), att = r.act(T, D), hbuf = r.act(T, c.dim_feedforward);
-  if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
-  if (!r.dry) {
-    if (bf) {
-      hipLaunchKernelGGL(rvq_sum_kernel<bf16_t>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (bf16_t*)q1.p, (bf16_t*)q2.p);
-    } else {
-      hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (float*)q1.p, (float*)q2.p);
-    }
-    KK_CHECK_LAUNCH();
-  }
-  MM_TRY(r.conv(m->proj_first, q1, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
-  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
-  r.note("quantized", x0);
-  if (!r.dry) {
-    if (bf)
-      hipLaunchKernelGGL(upsample_dw_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (const bf16_t*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (bf16_t*)xu.p);
-    else
-      hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (const float*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (float*)xu.p);
-    KK_CHECK_LAUNCH();
-    // xu is kept for the debug hook: the transformer updates x in place
-    if (hipMemcpyAsync(x.p, xu.p, (size_t)B * T * xu.ld * (bf ? 2 : 4), hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_decode: copy failed");
-  }
-  r.note("upsampled", xu);
-  // ---- transformer
-  MM_TRY(run_transformer(r, m->layers, x, n, qkv, att, hbuf));
-  r.note("transformer", x);
-  // ---- SEANet decoder
+  const int B = r.B, T = x.rows;
+  (void)who;
   Act y = r.act(T, m->init_conv.Cout);
   if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
   MM_TRY(r.conv(m->init_conv, x, y, (c.ksize - 1), 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
@@ -545,6 +518,157 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
     return 0;
   }
   MM_TRY(r.conv(m->final_conv, y, out, (c.last_ksize - 1), 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  return 0;
+}
+
+int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, Q = c.qdim, T = Nf * c.upsample_stride;
+  const bool bf = m->adt == KK_BF16;
+  // ---- split RVQ decode
+  Act q1 = r.act(Nf, Q), q2 = r.act(Nf, Q), x0 = r.act(Nf, D), xu = r.act(T, D), x = r.act(T, D);
+  Act n = r.act(T, D), qkv = r.act(T, 3 * D), att = r.act(T, D), hbuf = r.act(T, c.dim_feedforward);
+  if (r.oom) return kk_fail("kk_mimi_decode: workspace too small");
+  if (!r.dry) {
+    if (bf) {
+      hipLaunchKernelGGL(rvq_sum_kernel<bf16_t>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (bf16_t*)q1.p, (bf16_t*)q2.p);
+    } else {
+      hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(Nf, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, Nf, q1.ld, (float*)q1.p, (float*)q2.p);
+    }
+    KK_CHECK_LAUNCH();
+  }
+  MM_TRY(r.conv(m->proj_first, q1, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, x0, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
+  r.note("quantized", x0);
+  if (!r.dry) {
+    if (bf)
+      hipLaunchKernelGGL(upsample_dw_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (const bf16_t*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (bf16_t*)xu.p);
+    else
+      hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (const float*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (float*)xu.p);
+    KK_CHECK_LAUNCH();
+    // xu is kept for the debug hook: the transformer updates x in place
+    if (hipMemcpyAsync(x.p, xu.p, (size_t)B * T * xu.ld * (bf ? 2 : 4), hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_decode: copy failed");
+  }
+  r.note("upsampled", xu);
+  // ---- transformer
+  MM_TRY(run_transformer(r, m->layers, x, n, qkv, att, hbuf));
+  r.note("transformer", x);
+  // ---- SEANet decoder
+  return run_seanet(r, x, pcm, "kk_mimi_decode");
+}
+
+
+// ------------------------------------------------------------------------------------------------------------- streaming decode
+// Mimi.decode_step (mimi.py:163-168) / MimiStreamingDecoder (mimi.py:264-306).  Every convolution of the decode path is causal, so what
+// the reference's per-module state (StreamableConv1d._prev_xs, StreamableConvTranspose1d._prev_ys, conv.py:265-351) computes for a new
+// frame is exactly the offline causal convolution at those positions; it depends on a bounded look-back (init conv: 6 frames of the
+// 25 Hz stream, each decoder layer one more input sample).  So the stream keeps NO per-layer conv state: it keeps the previous quantised
+// frame (the 2x resampler looks back one), the KV caches of the transformer -- the one stateful module whose streaming result differs
+// from decode(): it sees the past only, the last `context` cached positions, and the positions of one step see each other
+// (no mask, transformer.py:79-104) -- and a WINDOW of the last SW transformer outputs, over which the offline SEANet kernels run each
+// step; the last frame's samples of that run are the step's output (window >= look-back + new rows, checked at create).
+constexpr int MIMI_SW = 16;  // transformer-output rows kept (25 Hz rows: 8 code frames)
+
+int seanet_lookback_rows(const kk_mimi_config& c) {
+  // rows of the 25 Hz stream an output sample can depend on, beyond its own: init conv k-1, then per layer one input sample of the
+  // transposed conv + (residual_ksize - 1) samples at the layer's rate -- converted to 25 Hz rows (rounded up)
+  double look = c.ksize - 1;
+  double rate = 1.0;  // samples per 25 Hz row at the input of the layer
+  for (int l = 0; l < c.n_ratios; ++l) {
+    look += 1.0 / rate;
+    rate *= c.ratios[l];
+    look += (double)(c.residual_ksize - 1) / rate;
+  }
+  look += (double)(c.last_ksize - 1) / rate;
+  return (int)ceil(look);
+}
+
+}  // namespace
+
+struct kk_mimi_stream {
+  kk_mimi* m = nullptr;
+  int max_batch = 0, max_pos = 0, context = 250;
+  float* xprev = nullptr;  // [maxB][dim]       previous quantised frame
+  float* tw = nullptr;     // [maxB][SW][dim]   last transformer outputs
+  float* kc = nullptr;     // [layers][maxB][max_pos][dim]
+  float* vc = nullptr;
+  float* rope = nullptr;   // [max_pos][hd/2][2]
+  int frames = 0, tw_rows = 0, pos = 0, B = 0;
+};
+
+namespace {
+
+int run_decode_step(Run& r, kk_mimi_stream* s, const int* codes, float* pcm_out) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, H = c.num_heads, hd = D / H;
+  const int win = s->frames > 0 ? 2 : 1;  // quantised frames the resampler sees: [previous, current]
+  const KKLen one{nullptr, 0, 1};
+  Act q1 = r.act(1, Q), q2 = r.act(1, Q), xc = r.act(1, D), xw = r.act(win, D), xu = r.act(win * us, D), x = r.act(us, D), xup = r.act(us, D);
+  Act n = r.act(us, D), qkv = r.act(us, 3 * D), att = r.act(us, D), hbuf = r.act(us, c.dim_feedforward);
+  const int Lw = std::min(MIMI_SW, s->tw_rows + us);  // rows the SEANet run covers after this step's rows are appended
+  Act xa = r.act(Lw, D);
+  long long spr = 1;
+  for (int l = 0; l < c.n_ratios; ++l) spr *= c.ratios[l];
+  float* pcm_w = (float*)r.raw((size_t)B * Lw * spr * 4);
+  float* shift = (float*)r.raw((size_t)B * MIMI_SW * D * 4);
+  if (r.oom) return kk_fail("kk_mimi_decode_step: workspace too small");
+  if (r.dry) {  // sizes only: the SEANet scratch of a full window
+    Act full = r.act(MIMI_SW, D);
+    (void)r.raw((size_t)B * MIMI_SW * spr * 4);
+    return run_seanet(r, full, nullptr, "kk_mimi_decode_step");
+  }
+  if (s->pos + us > s->max_pos) return kk_fail("kk_mimi_decode_step: the stream is longer than max_frames (kk_mimi_stream_create)");
+  // ---- quantizer.decode of the one new frame
+  hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(1, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, 1, q1.ld, (float*)q1.p, (float*)q2.p);
+  KK_CHECK_LAUNCH();
+  MM_TRY(r.conv(m->proj_first, q1, xc, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, xc, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
+  // ---- upsample.step: the resampler over [previous, current], its last `us` rows are the new ones
+  if (win == 2) MM_TRY(kk_launch_copy_slice(s->xprev, D, D, xw.p, xw.bs(), D, 0, D, 1, one, B, KK_F32, r.st));
+  MM_TRY(kk_launch_copy_slice(xc.p, xc.bs(), D, (float*)xw.p + (size_t)(win - 1) * D, xw.bs(), D, 0, D, 1, one, B, KK_F32, r.st));
+  MM_TRY(kk_launch_copy_slice(xc.p, xc.bs(), D, s->xprev, D, D, 0, D, 1, one, B, KK_F32, r.st));
+  hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(win * us, B), dim3(256), 0, r.st, (const float*)xw.p, m->up_w.p, D, xw.ld, win, us, (float*)xu.p);
+  KK_CHECK_LAUNCH();
+  const KKLen lus{nullptr, 0, us};
+  MM_TRY(kk_launch_copy_slice((float*)xu.p + (size_t)(win - 1) * us * D, xu.bs(), D, x.p, x.bs(), D, 0, D, us, lus, B, KK_F32, r.st));
+  MM_TRY(kk_launch_copy_slice(x.p, x.bs(), D, xup.p, xup.bs(), D, 0, D, us, lus, B, KK_F32, r.st));  // debug hook: the transformer updates x in place
+  r.note("upsampled", xup);
+  // ---- decoder_transformer with the KV caches (transformer.py:79-104,137-177)
+  for (size_t l = 0; l < m->layers.size(); ++l) {
+    const MimiLayer& L = m->layers[l];
+    float* kcl = s->kc + (size_t)l * s->max_batch * s->max_pos * D;
+    float* vcl = s->vc + (size_t)l * s->max_batch * s->max_pos * D;
+    MM_TRY(r.layernorm(x, n, L.n1w.p, L.n1b.p));
+    MM_TRY(r.conv(L.in_proj, n, qkv, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(kk_launch_rope_append((float*)qkv.p, us, H, H, hd, s->rope, s->pos, kcl, vcl, s->max_pos, B, r.st));
+    MM_TRY(kk_launch_attn_cache((const float*)qkv.p, us, H, H, hd, s->pos, kcl, vcl, s->max_pos, 1.0f / sqrtf((float)hd), (float*)att.p, 0, s->context, B, r.st));
+    MM_TRY(r.conv(L.out_proj, att, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));
+    MM_TRY(r.layernorm(x, n, L.n2w.p, L.n2b.p));
+    MM_TRY(r.conv(L.lin1, n, hbuf, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
+    MM_TRY(r.conv(L.lin2, hbuf, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));
+  }
+  r.note("transformer", x);
+  // ---- window of transformer outputs: drop the oldest rows when full, append the new ones
+  const long long twbs = (long long)MIMI_SW * D;
+  if (s->tw_rows + us > MIMI_SW) {
+    const int keep = MIMI_SW - us;
+    const KKLen lk{nullptr, 0, keep};
+    MM_TRY(kk_launch_copy_slice(s->tw + (size_t)(s->tw_rows - keep) * D, twbs, D, shift, twbs, D, 0, D, keep, lk, B, KK_F32, r.st));
+    MM_TRY(kk_launch_copy_slice(shift, twbs, D, s->tw, twbs, D, 0, D, keep, lk, B, KK_F32, r.st));
+    s->tw_rows = keep;
+  }
+  MM_TRY(kk_launch_copy_slice(x.p, x.bs(), D, s->tw + (size_t)s->tw_rows * D, twbs, D, 0, D, us, lus, B, KK_F32, r.st));
+  s->tw_rows += us;
+  // ---- decoder.step: the offline SEANet over the window; the step's samples are the last us * spr of the run
+  const KKLen lw{nullptr, 0, Lw};
+  MM_TRY(kk_launch_copy_slice(s->tw, twbs, D, xa.p, xa.bs(), D, 0, D, Lw, lw, B, KK_F32, r.st));
+  MM_TRY(run_seanet(r, xa, pcm_w, "kk_mimi_decode_step"));
+  const int nout = (int)(us * spr);
+  MM_TRY(kk_launch_copy_slice(pcm_w + (size_t)Lw * spr - nout, (long long)Lw * spr, nout, pcm_out, nout, nout, 0, nout, 1, one, B, KK_F32, r.st));
+  s->pos += us;
+  s->frames += 1;
   return 0;
 }
 
@@ -807,6 +931,69 @@ extern "C" int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int
   m->dbg.clear();
   Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   return run_decode(r, Nf, codes, pcm_out);
+}
+
+// ---- streaming decode (Mimi.decode_step / MimiStreamingDecoder, mimi.py:163-168,264-306)
+extern "C" int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out) {
+  if (!m || !m->finalized || !out || max_batch < 1 || max_frames < 1) return kk_fail("kk_mimi_stream_create: bad argument");
+  const kk_mimi_config& c = m->cfg;
+  const int hd = c.dim / c.num_heads;
+  if (hd != 64 && hd != 128) return kk_fail("kk_mimi_stream_create: head size must be 64 or 128");
+  if (seanet_lookback_rows(c) + c.upsample_stride > MIMI_SW) return kk_fail("kk_mimi_stream_create: the SEANet look-back exceeds the output window");
+  kk_mimi_stream* s = new (std::nothrow) kk_mimi_stream();
+  if (!s) return kk_fail("kk_mimi_stream_create: out of memory");
+  s->m = m; s->max_batch = max_batch; s->max_pos = max_frames * c.upsample_stride;
+  const size_t D = c.dim, kvn = (size_t)c.num_layers * max_batch * s->max_pos * D * 4;
+  std::vector<float> tab((size_t)s->max_pos * (hd / 2) * 2);
+  for (int p = 0; p < s->max_pos; ++p)
+    for (int i = 0; i < hd / 2; ++i) {
+      const float ang = (float)p * (float)pow((double)c.rope_base, -(double)i / (double)(hd / 2));  // the offline rope_kernel's angle
+      tab[((size_t)p * (hd / 2) + i) * 2] = cosf(ang);
+      tab[((size_t)p * (hd / 2) + i) * 2 + 1] = sinf(ang);
+    }
+  if (hipMalloc((void**)&s->xprev, (size_t)max_batch * D * 4) != hipSuccess || hipMalloc((void**)&s->tw, (size_t)max_batch * MIMI_SW * D * 4) != hipSuccess ||
+      hipMalloc((void**)&s->kc, kvn) != hipSuccess || hipMalloc((void**)&s->vc, kvn) != hipSuccess || hipMalloc((void**)&s->rope, tab.size() * 4) != hipSuccess ||
+      hipMemcpy(s->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    kk_mimi_stream_destroy(s);
+    return kk_fail("kk_mimi_stream_create: hipMalloc failed");
+  }
+  *out = s;
+  return 0;
+}
+extern "C" void kk_mimi_stream_destroy(kk_mimi_stream* s) {
+  if (!s) return;
+  for (float* p : {s->xprev, s->tw, s->kc, s->vc, s->rope})
+    if (p) (void)hipFree(p);
+  delete s;
+}
+extern "C" int kk_mimi_stream_reset(kk_mimi_stream* s) {  // MimiStreamingDecoder.reset (mimi.py:274-279)
+  if (!s) return kk_fail("kk_mimi_stream_reset: null stream");
+  s->frames = s->tw_rows = s->pos = 0;
+  s->B = 0;
+  return 0;
+}
+extern "C" int kk_mimi_stream_frames(const kk_mimi_stream* s) { return s ? s->frames : -1; }
+extern "C" size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B) {
+  if (!s || B < 1 || B > s->max_batch) return 0;
+  Run r{s->m, nullptr, B, nullptr, 0, 0, true, false};
+  r.adt = KK_F32;
+  kk_mimi_stream probe = *s;
+  probe.frames = 1;  // the two-frame resampler window
+  probe.tw_rows = MIMI_SW;
+  if (run_decode_step(r, &probe, nullptr, nullptr) != 0) return 0;
+  return r.used + 256;
+}
+// One frame of codes [B][nq] int32 -> pcm [B][samples_per_frame] float32; the stream's state lives in `s` (library-owned device memory).
+// B is fixed by the first step after create / reset.  fp32 kernels.
+extern "C" int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out) {
+  if (!s || !codes || !workspace || !pcm_out || B < 1 || B > s->max_batch) return kk_fail("kk_mimi_decode_step: bad argument");
+  if (s->frames > 0 && B != s->B) return kk_fail("kk_mimi_decode_step: the batch size of a stream is fixed until it is reset");
+  if (workspace_bytes < kk_mimi_stream_workspace_bytes(s, B)) return kk_fail("kk_mimi_decode_step: workspace too small");
+  s->B = B;
+  s->m->dbg.clear();
+  Run r{s->m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
+  r.adt = KK_F32;
+  return run_decode_step(r, s, codes, pcm_out);
 }
 
 extern "C" int kk_mimi_encode_frames(const kk_mimi* m, int N) { return (m && N > 0) ? mimi_encode_frames(m->cfg, N) : 0; }

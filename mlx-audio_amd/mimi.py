@@ -74,6 +74,9 @@ class Mimi:
 
     def __del__(self):
         try:
+            if getattr(self, "_sh", None) is not None:
+                self.lib.kk_mimi_stream_destroy(self._sh)
+                self._sh = None
             if getattr(self, "_h", None):
                 self.lib.kk_mimi_destroy(self._h)
                 self._h = None
@@ -145,6 +148,43 @@ class Mimi:
                                           C.c_void_p(codes.data_ptr())), "kk_mimi_encode")
         return codes
 
+    # ---- streaming (mimi.py:163-168): one frame of codes per call, the state lives in a library-owned stream object
+    def decode_step(self, codes, max_batch: int = 0, max_frames: int = 2048) -> torch.Tensor:
+        """codes [B, nq, 1] -> pcm [B, 1, 1920].  The first call (or the first after reset_stream) fixes B."""
+        if not self._final:
+            raise KokoroHipError("Mimi.decode_step: load_weights first")
+        codes = torch.as_tensor(codes).to(device=self.device, dtype=torch.int32)
+        if codes.ndim != 3 or codes.shape[1] != self.cfg.nq or codes.shape[2] != 1:
+            raise ValueError(f"codes must be [B, {self.cfg.nq}, 1], got {tuple(codes.shape)}")
+        B = codes.shape[0]
+        codes = codes[:, :, 0].contiguous()
+        with torch.cuda.device(self.device):
+            if getattr(self, "_sh", None) is None or self._s_maxb < B:
+                self.close_stream()
+                h = C.c_void_p()
+                check(self.lib.kk_mimi_stream_create(self._h, max(B, max_batch), max_frames, C.byref(h)), "kk_mimi_stream_create")
+                self._sh, self._s_maxb = h, max(B, max_batch)
+            need = int(self.lib.kk_mimi_stream_workspace_bytes(self._sh, B))
+            if need == 0:
+                raise KokoroHipError("kk_mimi_stream_workspace_bytes failed")
+            if getattr(self, "_sws", None) is None or self._sws.numel() < need:
+                self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            spf = int(self.lib.kk_mimi_samples_per_frame(self._h))
+            pcm = torch.empty((B, 1, spf), dtype=torch.float32, device=self.device)
+            self._last_B = B
+            check(self.lib.kk_mimi_decode_step(self._sh, self._stream(), B, C.c_void_p(codes.data_ptr()), C.c_void_p(self._sws.data_ptr()), self._sws.numel(),
+                                               C.c_void_p(pcm.data_ptr())), "kk_mimi_decode_step")
+        return pcm
+
+    def reset_stream(self) -> None:
+        if getattr(self, "_sh", None) is not None:
+            check(self.lib.kk_mimi_stream_reset(self._sh), "kk_mimi_stream_reset")
+
+    def close_stream(self) -> None:
+        if getattr(self, "_sh", None) is not None:
+            self.lib.kk_mimi_stream_destroy(self._sh)
+            self._sh = None
+
     def debug_fetch(self, name: str) -> torch.Tensor:
         rows, ch = C.c_int64(0), C.c_int64(0)
         check(self.lib.kk_mimi_debug_info(self._h, name.encode(), C.byref(rows), C.byref(ch)), "kk_mimi_debug_info")
@@ -152,3 +192,20 @@ class Mimi:
         out = torch.empty((B, rows.value, ch.value), dtype=torch.float32, device=self.device)
         check(self.lib.kk_mimi_debug_fetch(self._h, self._stream(), name.encode(), C.c_void_p(out.data_ptr())), "kk_mimi_debug_fetch")
         return out
+
+
+class MimiStreamingDecoder:
+    """mimi.py:264-306: keeps the codec's decode state across calls and decodes tokens frame by frame with `decode_step`."""
+
+    def __init__(self, mimi: Mimi) -> None:
+        self._mimi = mimi
+        self.reset()
+
+    def reset(self) -> None:
+        self._mimi.reset_stream()
+
+    def decode_frames(self, tokens) -> torch.Tensor:
+        tokens = torch.as_tensor(tokens)
+        if tokens.ndim == 2:
+            tokens = tokens[None]
+        return torch.cat([self._mimi.decode_step(tokens[:, :, t : t + 1]) for t in range(tokens.shape[-1])], dim=-1)

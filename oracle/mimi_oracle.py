@@ -202,3 +202,125 @@ class MimiOracle:
             inter["transformer"] = x.numpy()
             pcm = self.seanet_decoder(x, inter).numpy()
         return (pcm, inter) if return_inter else pcm
+
+
+class MimiStreamOracle:
+    """Streaming decode, restated with the reference's explicit per-module state (TEST INFRASTRUCTURE ONLY):
+      mimi.py:163-168            Mimi.decode_step = quantizer.decode -> upsample.step -> decoder_transformer(cache) -> decoder.step
+      mimi.py:264-306            MimiStreamingDecoder.reset / decode_frames (frame by frame, outputs concatenated)
+      conv.py:265-293            StreamableConv1d.step: first call left-pads ksize - stride zeros, `_prev_xs` carries the unconsumed input
+      conv.py:335-351            StreamableConvTranspose1d.step: the last ksize - stride outputs are held back (`_prev_ys`, bias removed
+                                 before it is added to the next step's head)
+      seanet.py:113-116,219-223,277-283   residual block / decoder layer / decoder .step (the skip add of equal lengths is a plain add)
+      transformer.py:79-104      Attention with a KV cache: RoPE offset = cache.offset, keys limited to the last `context` cached ones
+                                 plus the new block, NO mask (the positions of one step see each other)
+    The cache is mlx_lm-style (append, fetch everything): not in the reference tree -- upstream knowledge, PARITY UNPINNED."""
+
+    def __init__(self, w: dict, cfg: dict, context: int = 250):
+        self.o = MimiOracle(w, cfg)
+        self.cfg = cfg
+        self.context = context
+        self.reset()
+
+    def reset(self):
+        self.state = {}
+        self.kv = [None] * self.cfg["num_layers"]
+        self.offset = 0
+
+    # conv.py:265-293 (stride 1, dilation 1 in the decoder)
+    def conv_step(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
+        w = t(self.o.w[prefix + ".conv.conv.weight"])
+        b = t(self.o.w[prefix + ".conv.conv.bias"]) if prefix + ".conv.conv.bias" in self.o.w else None
+        k = w.shape[1]
+        if prefix not in self.state:
+            x = F.pad(x, (k - 1, 0))
+        else:
+            x = torch.cat([self.state[prefix], x], dim=-1)
+        nframes = max(x.shape[-1] + 1 - k, 0)
+        self.state[prefix] = x[..., nframes:]
+        if nframes == 0:
+            return x.new_zeros(x.shape[0], w.shape[0], 0)
+        return F.conv1d(x[..., : nframes - 1 + k], w.permute(0, 2, 1), b)
+
+    # conv.py:335-351
+    def convtr_step(self, x: torch.Tensor, prefix: str, stride: int, depthwise: bool = False) -> torch.Tensor:
+        w = t(self.o.w[prefix + ".convtr.convtr.weight"])
+        bkey = prefix + ".convtr.convtr.bias"
+        b = t(self.o.w[bkey]) if bkey in self.o.w else None
+        k = w.shape[1]
+        if depthwise:
+            ys = F.conv_transpose1d(x, w[0].transpose(0, 1)[:, None, :], None, stride=stride, groups=w.shape[2])
+        else:
+            ys = F.conv_transpose1d(x, w.permute(2, 0, 1), b, stride=stride)
+        if prefix in self.state:
+            prev = self.state[prefix]
+            if b is not None:
+                prev = prev - b[None, :, None]
+            pt = prev.shape[-1]
+            ys = torch.cat([ys[..., :pt] + prev, ys[..., pt:]], dim=-1)
+        inv = k - stride
+        ot = ys.shape[-1]
+        self.state[prefix] = ys[..., ot - inv :]
+        return ys[..., : ot - inv]
+
+    def transformer_step(self, x: torch.Tensor) -> torch.Tensor:
+        cfg, o = self.cfg, self.o
+        H = cfg["num_heads"]
+        x = x.transpose(1, 2)
+        Bn, T, C = x.shape
+        hd = C // H
+        pos = torch.arange(self.offset, self.offset + T, dtype=torch.float32)[:, None]
+        inv = torch.tensor(float(cfg["rope_base"]), dtype=torch.float32) ** (-torch.arange(0, hd // 2, dtype=torch.float32) / (hd // 2))
+        c, s = torch.cos(pos * inv[None]), torch.sin(pos * inv[None])
+
+        def rope(v):
+            out = torch.empty_like(v)
+            out[..., 0::2] = v[..., 0::2] * c - v[..., 1::2] * s
+            out[..., 1::2] = v[..., 0::2] * s + v[..., 1::2] * c
+            return out
+
+        for i in range(cfg["num_layers"]):
+            p = f"decoder_transformer.transformer.layers.{i}"
+            n1 = F.layer_norm(x, (C,), t(o.w[p + ".norm1.weight"]), t(o.w[p + ".norm1.bias"]), 1e-5)
+            qkv = (n1 @ t(o.w[p + ".self_attn.in_proj.weight"]).T).reshape(Bn, T, 3, H, hd)
+            q, k, v = [qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3)]
+            q, k = rope(q), rope(k)
+            if self.kv[i] is not None:
+                k = torch.cat([self.kv[i][0], k], dim=2)
+                v = torch.cat([self.kv[i][1], v], dim=2)
+            self.kv[i] = (k, v)
+            klen = k.shape[2]
+            tgt = T + min(self.context, klen - T)
+            k, v = k[:, :, klen - tgt :], v[:, :, klen - tgt :]
+            att = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1) @ v
+            att = att.permute(0, 2, 1, 3).reshape(Bn, T, C) @ t(o.w[p + ".self_attn.out_proj.weight"]).T
+            x = x + att * t(o.w[p + ".layer_scale_1.scale"])
+            n2 = F.layer_norm(x, (C,), t(o.w[p + ".norm2.weight"]), t(o.w[p + ".norm2.bias"]), 1e-5)
+            h = n2 @ t(o.w[p + ".gating.linear1.weight"]).T
+            h = 0.5 * h * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (h + 0.044715 * h ** 3)))
+            x = x + (h @ t(o.w[p + ".gating.linear2.weight"]).T) * t(o.w[p + ".layer_scale_2.scale"])
+        self.offset += T
+        return x.transpose(1, 2)
+
+    def seanet_step(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.conv_step(x, "decoder.init_conv1d")
+        for l, r in enumerate(self.cfg["ratios"]):
+            p = f"decoder.layers.{l}"
+            x = self.convtr_step(F.elu(x), p + ".upsample", r)
+            res = x
+            y = self.conv_step(F.elu(x), p + ".residuals.0.block.0")
+            y = self.conv_step(F.elu(y), p + ".residuals.0.block.1")
+            x = y + res
+        return self.conv_step(F.elu(x), "decoder.final_conv1d")
+
+    def decode_step(self, codes: np.ndarray, return_inter: bool = False):
+        """codes [B, nq, t] (t = 1 in MimiStreamingDecoder) -> pcm [B, 1, samples_per_frame * t]."""
+        with torch.no_grad():
+            x = self.o.quantizer_decode(np.asarray(codes))
+            x = self.convtr_step(x, "upsample.convtr", self.cfg["upsample_stride"], depthwise=True)
+            xt = self.transformer_step(x)
+            pcm = self.seanet_step(xt).numpy()
+        return (pcm, {"upsampled": x.numpy(), "transformer": xt.numpy()}) if return_inter else pcm
+
+    def decode_frames(self, codes: np.ndarray) -> np.ndarray:
+        return np.concatenate([self.decode_step(codes[:, :, i : i + 1]) for i in range(codes.shape[-1])], axis=-1)

@@ -164,3 +164,45 @@ def test_mimi_golden_fixture_without_oracle():
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
     codes = model.encode(torch.tensor(g["pcm_in"])).cpu().numpy()
     assert (codes == g["codes_out"]).mean() > 0.97  # identical up to near-tie flips of the argmin
+
+
+@pytest.mark.parametrize("which", ["tiny", "mimi_202407"])
+def test_mimi_streaming_decode_matches_stream_oracle(which):
+    """Mimi.decode_step / MimiStreamingDecoder (mimi.py:163-168,264-306) through kk_mimi_decode_step against MimiStreamOracle (the
+    reference's explicit conv / cache state): every frame's pcm within 1e-3 (fp32: measured ~1e-6), more frames than the output window
+    holds (the window slides), more cached positions than the tiny context (the key range slides), reset, and batch independence."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig, MimiStreamingDecoder
+
+    cfg = P.mimi_tiny_config() if which == "tiny" else P.mimi_config(32)
+    w = P.mimi_synth_checkpoint(cfg, 5)
+    rng = np.random.default_rng(9)
+    B, Nf = (2, 21) if which == "tiny" else (2, 12)
+    codes = rng.integers(0, cfg["bins"], (B, cfg["nq"], Nf))
+    orc = M.MimiStreamOracle(w, cfg)
+    model = Mimi(MimiConfig.from_dict(cfg), w)
+    spf = 1920 if which != "tiny" else int(np.prod(cfg["ratios"])) * cfg["upsample_stride"]
+    worst = 0.0
+    outs = []
+    for i in range(Nf):
+        ref, inter = orc.decode_step(codes[:, :, i : i + 1], return_inter=True)
+        got = model.decode_step(torch.tensor(codes[:, :, i : i + 1]))
+        torch.cuda.synchronize()
+        assert tuple(got.shape) == (B, 1, spf) == ref.shape
+        for name in ("upsampled", "transformer"):
+            e = err_stats(model.debug_fetch(name).cpu().numpy(), np.transpose(inter[name], (0, 2, 1)))
+            assert e["rel_max"] < 2e-4, (i, name, e)
+        e = err_stats(got.cpu().numpy(), ref)
+        worst = max(worst, e["max_abs"] / max(1.0, e["ref_max"]))
+        assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), (i, e)
+        outs.append(got.cpu().numpy())
+    report(f"mimi/stream/{which}", worst_rel=worst, frames=Nf)
+    # MimiStreamingDecoder: reset, then the same frames again in one call -> the same bits; item 1 alone -> the same bits
+    dec = MimiStreamingDecoder(model)
+    again = dec.decode_frames(torch.tensor(codes)).cpu().numpy()
+    np.testing.assert_array_equal(again, np.concatenate(outs, -1))
+    dec.reset()
+    alone = dec.decode_frames(torch.tensor(codes[1:2])).cpu().numpy()
+    np.testing.assert_array_equal(alone[0], again[1])
+    # streaming is NOT decode(): the offline transformer sees the whole sequence (no mask), the stream only the past
+    off = model.decode(torch.tensor(codes)).cpu().numpy()
+    assert np.abs(off - again).max() > 1e-4

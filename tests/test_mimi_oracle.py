@@ -70,3 +70,38 @@ def test_encode_finds_the_nearest_code_and_is_causal_before_the_transformer():
     p2[..., -200:] += 0.5  # the SEANet encoder is causal: early frames do not move
     _, i2 = orc.encode(p2, return_inter=True)
     np.testing.assert_array_equal(inter["seanet"][..., :6], i2["seanet"][..., :6])
+
+
+def test_streaming_restatement_properties():
+    """MimiStreamOracle (the reference's explicit per-module state, conv.py:265-351): the causal resampler and SEANet give, frame by frame,
+    exactly what the offline causal convolutions give at those positions -- the property the GPU stream is built on -- while the
+    transformer (cache, no mask) makes decode_step differ from decode(); one frame in, 1920 * prod(ratios) / 1920 samples out."""
+    import torch
+
+    cfg = P.mimi_tiny_config()
+    w = P.mimi_synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(0)
+    codes = rng.integers(0, cfg["bins"], (2, cfg["nq"], 9))
+    off = M.MimiOracle(w, cfg)
+    pcm_off, inter = off.decode(codes, return_inter=True)
+    st = M.MimiStreamOracle(w, cfg)
+    outs, ups, trs = [], [], []
+    for i in range(codes.shape[-1]):
+        p, it = st.decode_step(codes[:, :, i : i + 1], return_inter=True)
+        assert p.shape == (2, 1, pcm_off.shape[-1] // codes.shape[-1])
+        outs.append(p); ups.append(it["upsampled"]); trs.append(it["transformer"])
+    pcm_st = np.concatenate(outs, -1)
+    np.testing.assert_allclose(np.concatenate(ups, -1), inter["upsampled"], atol=1e-6)
+    with torch.no_grad():
+        again = off.seanet_decoder(torch.tensor(np.concatenate(trs, -1))).numpy()
+    np.testing.assert_allclose(pcm_st, again, atol=5e-6 * max(1.0, float(np.abs(again).max())))
+    assert np.abs(pcm_st - pcm_off).max() > 1e-3  # the streaming transformer sees the past only
+    # frame 0 has no past: its two positions see each other in both forms, so the first frame agrees... only if the sequence is one frame long
+    one = M.MimiStreamOracle(w, cfg).decode_step(codes[:, :, :1])
+    np.testing.assert_allclose(one, off.decode(codes[:, :, :1]), atol=5e-6 * max(1.0, float(np.abs(one).max())))
+    # reset gives the same stream again; a context shorter than the history changes later frames only
+    st.reset()
+    np.testing.assert_array_equal(st.decode_frames(codes), pcm_st)
+    short = M.MimiStreamOracle(w, cfg, context=4).decode_frames(codes)
+    np.testing.assert_array_equal(short[..., : 3 * one.shape[-1]], pcm_st[..., : 3 * one.shape[-1]])
+    assert np.abs(short - pcm_st).max() > 0
