@@ -239,6 +239,7 @@ int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_str
 void kk_mimi_stream_destroy(kk_mimi_stream* s);
 int kk_mimi_stream_reset(kk_mimi_stream* s); /* MimiStreamingDecoder.reset */
 int kk_mimi_stream_frames(const kk_mimi_stream* s);
+int kk_mimi_stream_set_context(kk_mimi_stream* s, int context); /* TransformerConfig.context, default 250 (mimi.py:55-77); fresh / reset stream only */
 size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B);
 int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);
 /* intermediates of the last decode / encode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3" (decode), "seanet", "transformer", "downsampled" (encode); [B][rows][channels] fp32 */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "kk_mimi_stream_destroy": (None, [_vp]),
     "kk_mimi_stream_reset": (_i, [_vp]),
     "kk_mimi_stream_frames": (_i, [_vp]),
+    "kk_mimi_stream_set_context": (_i, [_vp, _i]),
     "kk_mimi_stream_workspace_bytes": (_sz, [_vp, _i]),
     "kk_mimi_decode_step": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_encode_frames": (_i, [_vp, _i]),

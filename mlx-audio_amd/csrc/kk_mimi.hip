@@ -973,6 +973,13 @@ extern "C" int kk_mimi_stream_reset(kk_mimi_stream* s) {  // MimiStreamingDecode
   return 0;
 }
 extern "C" int kk_mimi_stream_frames(const kk_mimi_stream* s) { return s ? s->frames : -1; }
+// TransformerConfig.context (mimi.py:55-77: 250 for mimi_202407): cached positions a step may look back on.  Only between resets.
+extern "C" int kk_mimi_stream_set_context(kk_mimi_stream* s, int context) {
+  if (!s || context < 0) return kk_fail("kk_mimi_stream_set_context: bad argument");
+  if (s->frames != 0) return kk_fail("kk_mimi_stream_set_context: only on a fresh or reset stream");
+  s->context = context;
+  return 0;
+}
 extern "C" size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B) {
   if (!s || B < 1 || B > s->max_batch) return 0;
   Run r{s->m, nullptr, B, nullptr, 0, 0, true, false};

@@ -69,6 +69,74 @@ class Model:
         return np.concatenate([tf, af], 0), np.concatenate([tm, am], 0)
 
     # ---- sesame.py:689-817 (non-streaming branch)
+    def _prompt(self, contexts, prompts_ids, max_audio_length_ms):
+        toks, masks = [], []
+        for ctx, pid in zip(contexts, prompts_ids):
+            ft, fm = [], []
+            for seg in ctx:
+                a, b = self._tokenize_segment(seg, add_eos=True)
+                ft.append(a)
+                fm.append(b)
+            a, b = self._tokenize_text_ids(pid)
+            ft.append(a)
+            fm.append(b)
+            toks.append(np.concatenate(ft, 0))
+            masks.append(np.concatenate(fm, 0))
+        S = toks[0].shape[0]
+        if any(t.shape[0] != S for t in toks):
+            raise ValueError("all streams of a batch must have prompts of the same length")
+        max_audio_frames = int(max_audio_length_ms / 80)
+        max_seq_len = self.model.cfg["max_seq_len"] - max_audio_frames
+        if S >= max_seq_len:
+            raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_seq_len}")  # sesame.py:755-758
+        return np.stack(toks), np.stack(masks), max_audio_frames
+
+    def generate_stream(self, contexts: List[List[Segment]], prompts_ids: List[Sequence[int]], max_audio_length_ms: float = 90_000,
+                        temperature: float = 0.9, top_k: int = 50, seed: Optional[int] = 0, stop_on_eos: bool = True, streaming_interval: float = 2.0):
+        """`generate(..., stream=True)` of the reference (sesame.py:689-817): the same frame loop, but every `streaming_interval` seconds of
+        generated frames (sesame.py:719-721: int(streaming_interval * 12.5) frames) are decoded INCREMENTALLY by MimiStreamingDecoder
+        (`generate_result(..., stream=True)`, sesame.py:619-629) and yielded as a partial GenerationResult."""
+        from .mimi import MimiStreamingDecoder
+
+        B = len(prompts_ids)
+        tok, msk, max_audio_frames = self._prompt(contexts, prompts_ids, max_audio_length_ms)
+        interval = max(1, int(streaming_interval * 12.5))
+        dev = self.model.device
+        self.model.reset_caches()
+        self.model.set_graph_mode(True)
+        decoder = MimiStreamingDecoder(self._audio_tokenizer)
+        curr, cmask = torch.tensor(tok, device=dev), torch.tensor(msk, device=dev)
+        rng = np.random.default_rng(seed) if seed is not None else None
+        step_mask = torch.zeros((B, 1, self.n_cb + 1), dtype=torch.float32, device=dev)
+        step_mask[:, 0, : self.n_cb] = 1
+        samples, start = [], time.perf_counter()
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+
+        def result(frames):
+            audio = decoder.decode_frames(torch.stack(frames, dim=2))[:, 0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - start
+            secs = audio.shape[1] / self.sample_rate
+            return GenerationResult(audio=audio, samples=int(audio.shape[1]), sample_rate=self.sample_rate, token_count=len(frames),
+                                    processing_time_seconds=dt, real_time_factor=dt / secs if secs > 0 else 0.0)
+
+        for _ in range(max_audio_frames):
+            u = torch.tensor(rng.uniform(size=(B, self.n_cb)).astype(np.float32), device=dev) if rng is not None and temperature > 0 else None
+            sample = self.model.generate_frame(curr, cmask, temperature=temperature, top_k=top_k, uniforms=u)
+            if stop_on_eos:
+                done |= (sample == 0).all(dim=1)
+                if bool(done.all()):
+                    break
+            samples.append(sample.clone())
+            curr = torch.zeros((B, 1, self.n_cb + 1), dtype=torch.int32, device=dev)
+            curr[:, 0, : self.n_cb] = sample
+            cmask = step_mask
+            if len(samples) >= interval:
+                yield result(samples)
+                samples, start = [], time.perf_counter()
+        if samples:
+            yield result(samples)
+
     def generate(self, contexts: List[List[Segment]], prompts_ids: List[Sequence[int]], speaker: int = 0, max_audio_length_ms: float = 90_000,
                  temperature: float = 0.9, top_k: int = 50, seed: Optional[int] = 0, stop_on_eos: bool = True) -> GenerationResult:
         """One entry of `contexts` / `prompts_ids` per stream.  All prompts must assemble to the same number of frames."""

@@ -240,6 +240,14 @@ def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
     e = err_stats(res.audio.cpu().numpy(), ref_pcm)
     report("csm/e2e_tiny/pcm", **e)
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
+    # stream=True (sesame.py:689-817 with generate_result(stream=True), :619-629): the same frames in partial results of
+    # int(streaming_interval * 12.5) frames, decoded incrementally -- against the STREAMING Mimi oracle on the oracle loop's codes
+    parts = list(loop.generate_stream(ctx, prompts, max_audio_length_ms=80 * 6, temperature=0.0, stop_on_eos=False, streaming_interval=0.2))
+    assert [p.token_count for p in parts] == [2, 2, 2] and all(tuple(p.audio.shape) == (2, 2 * 1920) for p in parts)
+    ref_stream = MO.MimiStreamOracle(mw, mcfg).decode_frames(ref_codes)[:, 0]
+    es = err_stats(torch.cat([p.audio for p in parts], dim=1).cpu().numpy(), ref_stream)
+    report("csm/e2e_tiny/pcm_stream", **es)
+    assert es["max_abs"] <= 1e-3 * max(1.0, es["ref_max"]), es
 
 
 def test_csm_golden_fixture_without_oracle():

@@ -206,3 +206,13 @@ def test_mimi_streaming_decode_matches_stream_oracle(which):
     # streaming is NOT decode(): the offline transformer sees the whole sequence (no mask), the stream only the past
     off = model.decode(torch.tensor(codes)).cpu().numpy()
     assert np.abs(off - again).max() > 1e-4
+    if which == "tiny":  # a context shorter than the history: the key range slides (transformer.py:94-98)
+        from mlx_audio_amd import _lib
+
+        dec.reset()
+        _lib.check(model.lib.kk_mimi_stream_set_context(model._sh, 6), "set_context")
+        short = dec.decode_frames(torch.tensor(codes)).cpu().numpy()
+        ref_short = M.MimiStreamOracle(w, cfg, context=6).decode_frames(codes)
+        e = err_stats(short, ref_short)
+        report("mimi/stream/tiny_context6", **e)
+        assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]) and np.abs(short - again).max() > 1e-4
