@@ -159,9 +159,14 @@ __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int
 // dimension), whose partial sums are added in group order through LDS.
 // `causal`: 1 = query s sees keys 0 .. offset+s (index_causal_mask, sesame.py:41-48); 0 = every query of the block sees all offset+S
 // keys (Mimi's streaming transformer passes no mask, transformer.py:79-104).  `ctx` >= 0: only the last ctx CACHED keys (+ the block).
-__global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, const float* kc,
-                                                         const float* vc, int max_pos, float scale, float* out, int causal, int ctx) {
-  extern __shared__ __attribute__((aligned(16))) float sc[];  // [max_pos] scores, then [hd] q, then [G][hd] partial outputs
+// FUSE (single-token steps: S = 1, causal, no context limit): the RoPE of q and of the new key and the append of the new key / value row
+// happen HERE instead of in rope_append_kernel (one launch less per layer and step): q and the new k are rotated while they are staged in
+// LDS -- the same expressions, so the same bits as the two-kernel path --, the new row is the last key / value of the walk, and the first
+// query head of each kv group writes it to the cache for the steps to come (the other heads of the group never read that row here).
+template <bool FUSE>
+__global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, float* kc,
+                                                         float* vc, int max_pos, float scale, float* out, int causal, int ctx, const float* rope) {
+  extern __shared__ __attribute__((aligned(16))) float sc[];  // [max_pos] scores, [hd] q, [G][hd] partial outputs, [hd] new k, [hd] new v
   __shared__ float red[2];
   if (pos_dev) offset += *pos_dev;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
@@ -170,15 +175,39 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   const int mp4 = (max_pos + 3) & ~3;
   float* qs = sc + mp4;        // [hd]
   float* po = qs + hd;         // [G][hd]
+  float* kn = po + (512 / hd) * hd;  // [hd] (FUSE)
+  float* vn = kn + hd;               // [hd] (FUSE)
   const float* q = qkv + ((long long)b * S + s) * W + h * hd;
   const float* kb = kc + ((long long)b * max_pos + klo) * KV * hd + kvh * hd;
   const float* vb = vc + ((long long)b * max_pos + klo) * KV * hd + kvh * hd;
-  for (int e = tid; e < hd; e += 128) qs[e] = q[e];
+  const int jn = FUSE ? nk - 1 : -1;  // the key that is not in the cache yet
+  if (FUSE) {
+    const float* cs = rope + (long long)(offset + s) * (hd / 2) * 2;
+    const float* kq = qkv + ((long long)b * S + s) * W + (H + kvh) * hd;
+    const float* vq = qkv + ((long long)b * S + s) * W + (H + KV + kvh) * hd;
+    for (int i = tid; i < hd / 2; i += 128) {
+      const float c = cs[2 * i], sn = cs[2 * i + 1];
+      const float x0 = q[2 * i], x1 = q[2 * i + 1];
+      qs[2 * i] = x0 * c - x1 * sn;
+      qs[2 * i + 1] = x1 * c + x0 * sn;
+      const float k0 = kq[2 * i], k1 = kq[2 * i + 1];
+      kn[2 * i] = k0 * c - k1 * sn;
+      kn[2 * i + 1] = k1 * c + k0 * sn;
+    }
+    for (int e = tid; e < hd; e += 128) vn[e] = vq[e];
+  } else {
+    for (int e = tid; e < hd; e += 128) qs[e] = q[e];
+  }
   __syncthreads();
+  if (FUSE && h % (H / KV) == 0) {
+    float* kdst = kc + ((long long)b * max_pos + offset + s) * KV * hd + kvh * hd;
+    float* vdst = vc + ((long long)b * max_pos + offset + s) * KV * hd + kvh * hd;
+    for (int e = tid; e < hd; e += 128) { kdst[e] = kn[e]; vdst[e] = vn[e]; }
+  }
   const int hd4 = hd >> 2;
   float mx = -INFINITY;
   for (int j = tid; j < nk; j += 128) {
-    const float4* kr = (const float4*)(kb + (long long)j * KV * hd);
+    const float4* kr = j == jn ? (const float4*)kn : (const float4*)(kb + (long long)j * KV * hd);
     float d = 0.f;
     for (int e0 = 0; e0 < hd4; e0 += 16) {  // hd = 64 or 128: 16 independent loads per trip
       float4 kv[16];
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j = g; j < nk; j += G) {
     const float p = sc[j];
-    const float4 v = *(const float4*)(vb + (long long)j * KV * hd + 4 * e4);
+    const float4 v = j == jn ? *(const float4*)(vn + 4 * e4) : *(const float4*)(vb + (long long)j * KV * hd + 4 * e4);
     acc.x = __builtin_fmaf(p, v.x, acc.x);
     acc.y = __builtin_fmaf(p, v.y, acc.y);
     acc.z = __builtin_fmaf(p, v.z, acc.z);
@@ -231,8 +260,8 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   }
 }
 
-// dynamic LDS of attn_cache_kernel: scores (padded to 4) + q + G partial outputs of hd floats, G = 512 / hd
-static size_t attn_lds_bytes(int max_pos, int hd) { return ((size_t)((max_pos + 3) & ~3) + hd + (size_t)(512 / hd) * hd) * 4; }
+// dynamic LDS of attn_cache_kernel: scores (padded to 4) + q + G partial outputs of hd floats (G = 512 / hd) + the new k and v rows
+static size_t attn_lds_bytes(int max_pos, int hd) { return ((size_t)((max_pos + 3) & ~3) + hd + (size_t)(512 / hd) * hd + 2 * hd) * 4; }
 
 __global__ void advance_pos_kernel(int* pos, int by) { *pos += by; }
 
@@ -790,11 +819,17 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
     float* vc = st.vc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
     CS_TRY(r.lin(L.qkv, x, (long long)S * D, S, qkv, (long long)S * W, nullptr));
     if (!r.dry) {
-      hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
-      KK_CHECK_LAUNCH();
-      hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev, st.pos_dev ? 0 : offset, kc,
-                         vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1);
-      KK_CHECK_LAUNCH();
+      if (S == 1) {  // single-token step: RoPE + cache append inside the attention kernel
+        hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev,
+                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, st.rope.p);
+        KK_CHECK_LAUNCH();
+      } else {
+        hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
+        KK_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_cache_kernel<false>, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev,
+                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, (const float*)nullptr);
+        KK_CHECK_LAUNCH();
+      }
     }
     // h += o(att); x = RMSNorm(h) (post_attention_layernorm)
     CS_TRY(r.lin(L.o, att, (long long)S * H * hd, S, h, (long long)S * D, h, false, L.n2.p, x, a.rms_eps));
@@ -899,8 +934,8 @@ int kk_launch_rope_append(float* qkv, int S, int H, int KV, int hd, const float*
 int kk_launch_attn_cache(const float* qkv, int S, int H, int KV, int hd, int offset, const float* kc, const float* vc, int max_pos, float scale, float* out,
                          int causal, int ctx, int B, hipStream_t st) {
   if (hd != 64 && hd != 128) return kk_fail("attn_cache: head_dim must be 64 or 128");
-  hipLaunchKernelGGL(attn_cache_kernel, dim3(S, H, B), dim3(128), attn_lds_bytes(max_pos, hd), st, qkv, S, H, KV, hd, (const int*)nullptr, offset, kc, vc, max_pos,
-                     scale, out, causal, ctx);
+  hipLaunchKernelGGL(attn_cache_kernel<false>, dim3(S, H, B), dim3(128), attn_lds_bytes(max_pos, hd), st, qkv, S, H, KV, hd, (const int*)nullptr, offset,
+                     const_cast<float*>(kc), const_cast<float*>(vc), max_pos, scale, out, causal, ctx, (const float*)nullptr);
   KK_CHECK_LAUNCH();
   return 0;
 }

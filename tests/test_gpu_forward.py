@@ -176,6 +176,22 @@ def test_max_context_and_single_phoneme_match_oracle():
         assert r["stage_worst"][k] < 2e-4, (k, r["stage_worst"][k])
 
 
+def test_empty_phoneme_string_matches_oracle():
+    """`Model.__call__("")` in the reference: no phoneme survives the vocabulary filter (kokoro.py:128-130), input_ids = [[0, 0]]
+    (kokoro.py:135): T = 2, BOS and EOS only.  Runs next to an ordinary utterance; free-running durations (>= 1 frame per token)."""
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(41)
+    utts = [[], rng.integers(1, 178, 9).tolist()]
+    r = _run_pair(cfg, w, utts, [1.0, 1.0], seed=3, tag="empty")
+    assert r["lens"] == [2, 11] and r["Fs"][0] >= 2
+    np.testing.assert_array_equal(r["pred"][0][:2], r["o_dur"][0])
+    for k in ("bert_dur", "d", "t_en", "en", "asr", "F0_pred", "N_pred", "dec_out"):
+        assert r["stage_worst"][k] < 2e-4, (k, r["stage_worst"][k])
+    n = r["o_audio"][0].shape[0]
+    assert n == 600 * r["Fs"][0] and np.all(r["wav"][0, n:] == 0) and np.isfinite(r["wav"]).all()
+
+
 def test_frames_past_fmax_are_dropped_and_reported():
     """kk_forward realises the predicted durations on the device; an utterance that needs more than Fmax frames is cut at
     Fmax (nframes reports what was produced, samples past 600 * nframes are zero, nothing overruns the buffers)."""
