@@ -219,7 +219,9 @@ def main():
             out["p50_latency_note"] = "one 128-phoneme utterance (16.25 s audio), kk_forward + sync, median of 10 after 2 warm-ups"
         pmc = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(args.dtype)
+            # PMC byte counts were taken at one batch size per configuration: B = 32 for the bf16 / fp32 entries, B = 64 for config 5
+            key, pmc_batch = ("bfloat16+fp8 (config 5, B=64, r01_i)", 64) if args.quantized else (args.dtype, 32)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(key) if B == pmc_batch else None
         except Exception:
             pmc = None
         if prof is not None:
@@ -234,8 +236,11 @@ def main():
             if prof.get("linear_mxfp8", {}).get("ms", 0) > 0:
                 q = prof["linear_mxfp8"]  # activation pre-pass + block-scaled fp8 product, bracketed together
                 qa = q["flops"] / (q["ms"] * 1e-3) / 1e12
+                qt = None
+                if pmc and "linear_mxfp8" in pmc:  # product + activation pre-pass, like the bracket
+                    qt = sum(pmc[k]["fetch_raw_bytes_per_launch"] + pmc[k]["write_bytes_per_launch"] for k in ("linear_mxfp8", "mxfp8_quant_rows"))
                 out["roofline_linear_mxfp8"] = {"bound": "mfma", "achieved": qa, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": qa / PEAK_FP8_TFLOPS,
-                                                "launches_per_step": q["launches"] / args.steps, "ms_per_step": q["ms"] / args.steps}
+                                                "traffic": qt, "launches_per_step": q["launches"] / args.steps, "ms_per_step": q["ms"] / args.steps}
             out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma" if conv is prof["conv_mfma"] else "conv_generic (fp32 VALU implicit GEMM)",
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "launches_per_step": conv["launches"] / args.steps, "ms_per_step": conv["ms"] / args.steps}
