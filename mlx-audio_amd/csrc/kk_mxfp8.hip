@@ -115,7 +115,18 @@ __global__ __launch_bounds__(256) void linear_mxfp8_kernel(KKFp8Args a) {
   const int wm = wv >> 1, wn = wv & 1;
   const int KS = a.K >> 6;
   const int MB = (a.M + 31) >> 5, NB = a.N >> 5;
-  const int mb0 = blockIdx.y * 4 + wm * 2, nb0 = blockIdx.x * 4 + wn * 2;
+  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive ids must NOT be the
+  // column blocks of one row block -- every XCD would then fetch every activation fragment.  The linear id is re-dealt so that an XCD
+  // walks whole row blocks (all column blocks of a row block on one L2) in id order.
+  const int nbx = gridDim.x, nby = gridDim.y, total = nbx * nby;
+  int lid = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int per = total / 8, rem = total - per * 8;  // the first `rem` XCDs own one tile more
+    const int xcd = lid & 7, idx = lid >> 3;
+    lid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int by = lid / nbx, bx = lid - by * nbx;
+  const int mb0 = by * 4 + wm * 2, nb0 = bx * 4 + wn * 2;
   if (mb0 >= MB || nb0 >= NB) return;  // whole wave; no barriers in this kernel
   long long fa[2], fb[2];
 #pragma unroll
@@ -130,37 +141,46 @@ __global__ __launch_bounds__(256) void linear_mxfp8_kernel(KKFp8Args a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  Frag A[2], Bf[2];
+  // operands of k-steps ks + 1 and ks + 2 are in flight while the MFMAs of ks run (an L2 round trip is ~5x one k-step of MFMAs)
+  Frag A0[2], B0[2], A1[2], B1[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    A[i] = load_frag(a.aq, a.as, fa[i], lane);
-    Bf[i] = load_frag(a.wq, a.ws, fb[i], lane);
+    A0[i] = load_frag(a.aq, a.as, fa[i], lane);
+    B0[i] = load_frag(a.wq, a.ws, fb[i], lane);
+    A1[i] = load_frag(a.aq, a.as, fa[i] + (KS > 1 ? 1 : 0), lane);
+    B1[i] = load_frag(a.wq, a.ws, fb[i] + (KS > 1 ? 1 : 0), lane);
   }
   for (int ks = 0; ks < KS; ++ks) {
-    Frag An[2], Bn[2];
-    const int kn = ks + 1 < KS ? ks + 1 : ks;
+    Frag A2[2], B2[2];
+    const int kn = ks + 2 < KS ? ks + 2 : KS - 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      An[i] = load_frag(a.aq, a.as, fa[i] + kn, lane);
-      Bn[i] = load_frag(a.wq, a.ws, fb[i] + kn, lane);
+      A2[i] = load_frag(a.aq, a.as, fa[i] + kn, lane);
+      B2[i] = load_frag(a.wq, a.ws, fb[i] + kn, lane);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(as_v8i(A[i]), as_v8i(Bf[j]), acc[i][j], 0 /*A e4m3*/, 0 /*B e4m3*/, 0,
-                                                                    A[i].s, 0, Bf[j].s);
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(as_v8i(A0[i]), as_v8i(B0[j]), acc[i][j], 0 /*A e4m3*/, 0 /*B e4m3*/, 0,
+                                                                    A0[i].s, 0, B0[j].s);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      A[i] = An[i];
-      Bf[i] = Bn[i];
+      A0[i] = A1[i]; B0[i] = B1[i];
+      A1[i] = A2[i]; B1[i] = B2[i];
     }
   }
-  // epilogue: C/D layout of the 32x32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  const int rows_per_item = a.rows_per_item;
+  // epilogue: C/D layout of the 32x32 forms: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // A 32-row block crosses at most one utterance boundary when rows_per_item >= 32: one division and two length loads per row block
+  // (a division and a length load per ROW, 64 of each per lane, was a large part of this kernel's time).
+  const int rpi = a.rows_per_item;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (mb0 + i >= MB) continue;
+    const int m0 = (mb0 + i) * 32;
+    const int b0 = m0 / rpi, t0 = m0 - b0 * rpi;
+    const int nitems = (a.M + rpi - 1) / rpi;
+    const int len0 = kk_len(a.lout, b0), len1 = kk_len(a.lout, b0 + 1 < nitems ? b0 + 1 : b0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (nb0 + j >= NB) continue;
@@ -168,11 +188,19 @@ __global__ __launch_bounds__(256) void linear_mxfp8_kernel(KKFp8Args a) {
       const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (mb0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int dr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + dr;
         if (m >= a.M) continue;
-        const int b = m / rows_per_item, t = m - b * rows_per_item;
+        bool valid;
+        if (rpi >= 32) {
+          const int t = t0 + dr;
+          valid = t < rpi ? t < len0 : t - rpi < len1;
+        } else {
+          const int bb = m / rpi;
+          valid = m - bb * rpi < kk_len(a.lout, bb);
+        }
         float v = 0.f;
-        if (t < kk_len(a.lout, b)) {
+        if (valid) {
           v = acc[i][j][r] + bias;
           if (a.act == KK_ACT_GELU) v = gelu_erf(v);
         }
