@@ -83,8 +83,26 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
-  const int b = blockIdx.z / nphase, phase = blockIdx.z - b * nphase;
-  const int q0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: the dispatcher deals workgroup ids (x fastest, then y, z) round-robin to the 8 XCDs, each with its own L2.
+  // Neighbouring row tiles share their halo rows (up to 50 of 192 + 50 for k = 11, dilation 5) and the column blocks of one row tile share
+  // the whole X slab, so the flat id is re-dealt: an XCD walks a contiguous run of (utterance, row tile) pairs, column blocks innermost.
+  int bx, by, bz;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    int lid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int per = total / 8, rem = total - per * 8;
+    const int xcd = lid & 7, idx = lid >> 3;
+    if (!(a.dbg & 4)) lid = xcd * per + (xcd < rem ? xcd : rem) + idx;  // dbg bit 2 (KK_MFMA_NOXCD=1): the dispatcher's own order, for A/B timing
+    else { by = blockIdx.y; bx = blockIdx.x; bz = blockIdx.z; }
+    if (!(a.dbg & 4)) {
+      by = lid % gy;  // column blocks innermost
+      const int t = lid / gy;
+      bx = t % gx;
+      bz = t / gx;
+    }
+  }
+  const int b = bz / nphase, phase = bz - b * nphase;
+  const int q0 = bx * BM, n0 = by * BN;
   const int Lin = kk_len(a.lin, b), Lout = kk_len(a.lout, b);
 
   // taps: input row of output q for tap t is q + off0 + t*dstep ; weight slice widx0 + t*wstep
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // B fragments of one (tap, slab) iteration: [ni][ks], loaded from the fragment-order pack one iteration ahead.  Named
     // scalars, not an array (hipcc put a lambda-captured register array in scratch once already).
     uint4 q00, q01, q02, q03, q10, q11, q12, q13;
-    const int nb = blockIdx.y;
+    const int nb = by;
     auto frag_ptr = [&](int it) __attribute__((always_inline)) -> const uint4* {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
       // pack order: [tap][n block][chunk][wc][ni][ks][lane] x 16 bytes
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (n0 + col < a.Cout) {
       const float v = red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col] + red[(2 * 2 + which) * 128 + col] +
                       red[(3 * 2 + which) * 128 + col];
-      const int tile = blockIdx.x * nphase + phase;
+      const int tile = bx * nphase + phase;
       a.stat_part[(((long long)b * a.stat_ntiles + tile) * 2 + which) * a.Cout + n0 + col] = v;
     }
   }
@@ -544,7 +562,11 @@ int launch_one(const KKMfmaArgs& a, int B, hipStream_t st) {
   }
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
   dim3 grid(kk_cdiv(a.Q, 2 * WM), a.CoutP / BN, B * nphase);
-  hipLaunchKernelGGL((conv_mfma4_kernel<TO, WM, NRM>), grid, dim3(256), G::LDS_BYTES, st, a);
+  static int noxcd = -1;
+  if (noxcd < 0) noxcd = getenv("KK_MFMA_NOXCD") ? 1 : 0;
+  KKMfmaArgs a2 = a;
+  if (noxcd) a2.dbg |= 4;
+  hipLaunchKernelGGL((conv_mfma4_kernel<TO, WM, NRM>), grid, dim3(256), G::LDS_BYTES, st, a2);
   KK_CHECK_LAUNCH();
   return 0;
 }
