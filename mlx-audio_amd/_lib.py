@@ -138,6 +138,14 @@ def load():
             f"{path} not found: build it with `python mlx-audio_amd/build.py` (hipcc, gfx950). "
             "The Kokoro hot path has no CPU or PyTorch fallback."
         )
+    # torch brings its own copy of the HIP runtime (torch/lib/libamdhip64.so).  If this library were loaded first it would bind to the system
+    # copy under /opt/rocm, torch would then load its own, and the process would hold TWO HIP runtimes: the first hipMalloc of kk_finalize
+    # fails (seen with `python __graft_entry__.py smoke`, where build() loads the library before anything imports torch).  Importing torch
+    # first makes its runtime the one this library's libamdhip64 dependency resolves to.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

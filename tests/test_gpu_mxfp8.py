@@ -108,7 +108,7 @@ CASES = [("albert_qkv", 3, 130, 768, 2304, 0), ("albert_ffn_gelu", 2, 130, 768, 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_linear_matches_oracle(lib, case):
     name, B, rows, K, N, act = case
-    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    rng = np.random.default_rng(__import__("zlib").crc32(name.encode()) % 1000)  # (hash() of a str changes from process to process)
     M = B * rows
     x = MX.bf16_round((rng.standard_normal((M, K)) * 1.5).astype(np.float32))
     w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
@@ -124,8 +124,9 @@ def test_linear_matches_oracle(lib, case):
         want[b * rows + lens[b] : (b + 1) * rows] = 0.0
     assert (got[:, N:] == 7.0).all()  # the pitch padding of the destination is not touched
     d = np.abs(got[:, :N] - want)
-    # fp32 accumulation in another order, then ONE bf16 rounding (2^-9 relative) of the stored value
-    bound = np.abs(want) * 2.0**-8 + 2e-5 * np.abs(want).max()
+    # fp32 accumulation in another order, then ONE bf16 rounding of the stored value: when the two sums straddle a rounding boundary the
+    # stored values differ by a whole bf16 ulp, up to 2^-7 of the value
+    bound = np.abs(want) * 2.0**-7 + 2e-5 * np.abs(want).max()
     report(f"mxfp8/{name}", **err_stats(got[:, :N], want))
     assert (d <= bound).all(), float((d - bound).max())
     # and the format's own distance from the unquantised product, for the record
