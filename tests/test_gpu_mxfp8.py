@@ -206,3 +206,40 @@ def test_quantised_model_runs_fp8_and_tracks_the_oracle():
             # bf16 rounding of the activations flips e4m3 rounding decisions, 12 layers deep) stays well under the format's distance
             assert res[("fp8", name, b, "mxfp8")] < 0.5 * res[("fp8", name, b, "fp32")] + 0.01, (name, b, res[("fp8", name, b, "mxfp8")])
             assert res[("bf16", name, b, "fp32")] < 0.03, (name, b)
+
+
+def test_load_model_on_an_8bit_checkpoint_engages_the_fp8_path(tmp_path):
+    """The reference's load path for `*-8bit` checkpoints (tts/utils.py:241-260): config["quantization"] + uint32 `weight` / `scales` / `biases`
+    triplets on disk.  load_model dequantises them (quant.py), hands the group size to the engine (kk_set_quantization) and, in bf16 mode,
+    all six eligible linears run on the fp8 kernels; in fp32 mode (the parity path) none does.  The audio is finite and the durations agree
+    with an engine built directly from the dequantised weights."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    from mlx_audio_amd.engine import KokoroEngine
+    from mlx_audio_amd.quant import dequantize_checkpoint, quantize_checkpoint
+    from mlx_audio_amd.utils import load_model
+
+    cfg = P.tiny_config()
+    cfg["vocab"] = P.load_vocab()
+    w = P.synth_checkpoint(cfg, 0)
+    wq = quantize_checkpoint(w, 64, 8)
+    assert wq["bert_encoder.weight"].dtype == np.uint32 and "bert_encoder.scales" in wq
+    d = tmp_path / "kokoro-8bit"
+    d.mkdir()
+    json.dump(dict(cfg, model_type="kokoro", quantization={"group_size": 64, "bits": 8}), open(d / "config.json", "w"))
+    save_file({k: np.ascontiguousarray(v) for k, v in wq.items()}, str(d / "model.safetensors"))
+    ps = "hɛlˈoʊ wˈɜɹld"
+    ref_s = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "af_heart_rows.npz"))["rows"][3][None]  # any real style row
+    model = load_model(str(d), compute_dtype="bfloat16")
+    assert model.engine.lib.kk_quantized_layers(model.engine._h) == 6
+    out = model(ps, ref_s, 1.0, return_output=True)
+    assert torch.isfinite(out.audio).all() and out.audio.shape[1] == 600 * int(out.pred_dur.sum())
+    direct = KokoroEngine({k: v for k, v in cfg.items() if k != "vocab"}, dequantize_checkpoint(wq, 64, 8), compute_dtype="bfloat16",
+                          quantization={"group_size": 64, "bits": 8})
+    ids, lens, Tmax = direct.pack_ids([model._ids(ps)])
+    pred = direct.forward_text(ids, lens, torch.tensor(ref_s, device=direct.device), torch.ones(1, device=direct.device))
+    np.testing.assert_array_equal(pred.cpu().numpy()[0, : int(lens[0])], out.pred_dur.cpu().numpy())
+    m32 = load_model(str(d), compute_dtype="float32")  # the exact path never quantises
+    assert m32.engine.lib.kk_quantized_layers(m32.engine._h) == 0
