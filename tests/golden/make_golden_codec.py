@@ -23,7 +23,8 @@ codes = rng.integers(0, mcfg["bins"], (2, mcfg["nq"], 9)).astype(np.int32)
 pcm_in = (0.3 * rng.standard_normal((2, 1, 1920 * 5 + 321))).astype(np.float32)
 orc = M.MimiOracle(mw, mcfg)
 np.savez_compressed(os.path.join(HERE, "mimi_tiny_case.npz"), weights_seed=11, codes=codes, pcm_out=orc.decode(codes).astype(np.float32),
-                    pcm_in=pcm_in, codes_out=orc.encode(pcm_in).astype(np.int32))
+                    pcm_in=pcm_in, codes_out=orc.encode(pcm_in).astype(np.int32),
+                    pcm_stream=M.MimiStreamOracle(mw, mcfg).decode_frames(codes).astype(np.float32))  # Mimi.decode_step, frame by frame
 
 # ---- CSM (tiny): prompt block + 3 greedy frames
 ccfg = P.csm_tiny_config()

@@ -164,6 +164,13 @@ def test_mimi_golden_fixture_without_oracle():
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
     codes = model.encode(torch.tensor(g["pcm_in"])).cpu().numpy()
     assert (codes == g["codes_out"]).mean() > 0.97  # identical up to near-tie flips of the argmin
+    # the streaming decode of the same codes (Mimi.decode_step frame by frame, MimiStreamingDecoder)
+    from mlx_audio_amd.mimi import MimiStreamingDecoder
+
+    st = MimiStreamingDecoder(model).decode_frames(torch.tensor(g["codes"])).cpu().numpy()
+    es = err_stats(st, g["pcm_stream"])
+    report("mimi/golden/pcm_stream", **es)
+    assert es["max_abs"] <= 1e-3 * max(1.0, es["ref_max"]), es
 
 
 @pytest.mark.parametrize("which", ["tiny", "mimi_202407"])
