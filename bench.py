@@ -54,6 +54,57 @@ def cpu_baseline(cfg, w, utt, ref_s):
             "sample": f"1 utterance of the same workload (T=130, F=650, 16.25 s audio) in {dt:.1f} s; oracle/kokoro_oracle.py, torch-CPU fp32"}
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh child processes of this script, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), BEFORE this process makes any GPU call -- it never does:
+    it only waits.  Rank 0 inherits stdout, so its single JSON line is this command's output; the other ranks' stdout goes to stderr.
+    Returns non-zero if any rank failed."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+            rc = rc or (c if c > 0 else 1)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Launcher rehearsal without a GPU (tests/test_parallel_cpu.py): rendezvous over gloo, the bench's barrier + MAX-over-ranks
+    timing reduction and rank 0's JSON line -- everything around the timed region, none of the engine."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher rehearsal, no GPU work)", "value": 0.0, "unit": "audio-sec/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_over_ranks": float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,13 +119,21 @@ def main():
                     help="BASELINE config 5: the checkpoint goes through the MLX 8-bit group quantisation (group 64) of the reference's predicate and "
                          "its linears run on the fp8 matrix instruction; use with --batch 64.  The default run is config 2 (the headline).")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU (gloo): rendezvous, barrier, MAX reduction, rank 0's line")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched (or will touch) a GPU.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:  # n_gpus in the JSON line can never disagree with --gpus
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} (or unset WORLD_SIZE)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

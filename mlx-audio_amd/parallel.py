@@ -42,29 +42,40 @@ def gather_waveforms(local: torch.Tensor, out_root: Optional[torch.Tensor], dist
 
 
 def gather_ragged(local: torch.Tensor, nsamples: torch.Tensor, dist, dst: int = 0):
-    """Variable-length gather (RCCL has no gatherv): all_gather the per-utterance sample counts, then every rank
-    sends its [B, Nmax_local] block trimmed to its own longest utterance.  Returns (list of 1-D waveforms in global
-    order) on `dst`, None elsewhere."""
+    """Variable-length gather (RCCL has no gatherv).  Ranks may hold DIFFERENT numbers of utterances (the shards `shard_range` deals
+    when the batch does not divide by the world size): first the per-rank batch sizes are all-gathered, then the per-utterance sample
+    counts (padded to the largest batch), then every rank sends its [B_r, Nmax_r] block trimmed to its own longest utterance.
+    Returns the list of 1-D waveforms in global order on `dst`, None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    B = local.shape[0]
-    counts = [torch.empty_like(nsamples) for _ in range(world)]
-    dist.all_gather(counts, nsamples)
+    B = int(local.shape[0])
+    if int(nsamples.numel()) != B:
+        raise ValueError(f"gather_ragged: {B} waveforms but {int(nsamples.numel())} sample counts")
+    nb = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(nb, torch.tensor([B], dtype=torch.int64, device=local.device))
+    Bs = [int(t.item()) for t in nb]
+    Bmax = max(Bs)
+    mine = torch.zeros(Bmax, dtype=nsamples.dtype, device=nsamples.device)
+    mine[:B] = nsamples
+    counts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine)
+    counts = [c[: Bs[r]] for r, c in enumerate(counts)]
     widths = [int(c.max().item()) if c.numel() else 0 for c in counts]
     if rank == dst:
-        bufs = [torch.empty((B, widths[r]), dtype=local.dtype, device=local.device) for r in range(world)]
+        bufs = [torch.empty((Bs[r], widths[r]), dtype=local.dtype, device=local.device) for r in range(world)]
         reqs = []
         for r in range(world):
             if r == dst:
                 bufs[r].copy_(local[:, : widths[r]])
-            elif widths[r] > 0:
+            elif widths[r] > 0 and Bs[r] > 0:
                 reqs.append(dist.irecv(bufs[r], src=r))
         for q in reqs:
             q.wait()
         out = []
         for r in range(world):
-            for b in range(B):
-                out.append(bufs[r][b, : int(counts[r][b].item())])
+            cr = counts[r].tolist()
+            for b in range(Bs[r]):
+                out.append(bufs[r][b, : int(cr[b])])
         return out
-    if widths[rank] > 0:
+    if widths[rank] > 0 and B > 0:
         dist.send(local[:, : widths[rank]].contiguous(), dst=dst)
     return None

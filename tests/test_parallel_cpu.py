@@ -74,6 +74,20 @@ def _worker(rank, world, port, q):
                     ok &= bool(torch.equal(rag[r * B + b], exp))
         else:
             ok &= rag is None
+        # ragged with a DIFFERENT number of utterances per rank (7 utterances over 2 ranks: shards of 4 and 3)
+        lo, hi = par.shard_range(7, world, rank)
+        Bl = hi - lo
+        loc = torch.arange(Bl * N, dtype=torch.float32).reshape(Bl, N) + 1000 * rank
+        ns = torch.tensor([5 + 3 * (lo + b) for b in range(Bl)], dtype=torch.int32)
+        rag = par.gather_ragged(loc, ns, dist)
+        if rank == 0:
+            ok &= len(rag) == 7
+            for g in range(7):
+                r = next(k for k in range(world) if par.shard_range(7, world, k)[0] <= g < par.shard_range(7, world, k)[1])
+                b = g - par.shard_range(7, world, r)[0]
+                Br = par.shard_range(7, world, r)[1] - par.shard_range(7, world, r)[0]
+                exp = (torch.arange(Br * N, dtype=torch.float32).reshape(Br, N) + 1000 * r)[b, : 5 + 3 * g]
+                ok &= bool(torch.equal(rag[g], exp))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -91,3 +105,39 @@ def test_gather_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE")}
+    return env
+
+
+def test_bench_launcher_spawns_n_ranks_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment starts two ranks by itself (the launcher process never touches a GPU),
+    they rendezvous on 127.0.0.1, and exactly ONE JSON line -- rank 0's, with n_gpus == --gpus -- comes out on stdout."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["max_over_ranks"] == 2.0  # MAX over ranks of (rank + 1)
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    # and under a torchrun-style environment that matches, the same script runs as a rank
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and '"n_gpus": 1' in r.stdout
