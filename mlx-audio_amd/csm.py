@@ -74,6 +74,7 @@ class SesameModel:
     def setup_caches(self, max_batch_size: int) -> None:
         with torch.cuda.device(self.device):
             check(self.lib.kk_csm_setup_caches(self._h, int(max_batch_size)), "kk_csm_setup_caches")
+        self._gbuf = {}  # the library dropped its captured graphs with the old caches; their staging buffers go with them
         self._enabled = True
 
     def caches_are_enabled(self) -> bool:

@@ -1039,6 +1039,14 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
 // SesameModel.setup_caches / reset_caches (sesame.py:320-345): device KV caches for `max_batch` items; positions restart at 0
 extern "C" int kk_csm_setup_caches(kk_csm* m, int max_batch) {
   if (!m || !m->finalized || max_batch < 1) return kk_fail("kk_csm_setup_caches: bad argument");
+  // captured frame steps have the OLD cache / logits pointers baked in: drop every graph before the buffers they point at are freed
+  // (a replay after a second setup_caches would read and write freed memory)
+  for (auto& g : m->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  m->graphs.clear();
+  (void)hipDeviceSynchronize();  // nothing in flight may still use the caches about to be freed
   for (Stack* s : {&m->bb, &m->dec}) {
     if (s->kc) (void)hipFree(s->kc);
     if (s->vc) (void)hipFree(s->vc);

@@ -46,6 +46,57 @@ def load_voice_tensor(path: str) -> np.ndarray:
     raise ValueError(f"unsupported voice file: {path}")
 
 
+PHONEME_LIMIT = 510  # phonemes per forward (512 positions minus <bos>/<eos>, kokoro.py:131-134)
+HALF_FRAMES_PER_SECOND = 80
+# where a too-long token run may be cut, best first: sentence ends, then clause marks, then commas / dashes; a closing bracket or quote
+# directly behind the mark stays with it
+SPLIT_TIERS = ("!.?…", ":;", ",—")
+CLOSERS = (")", "”")
+
+
+def _phoneme_text(tokens) -> str:
+    """The phoneme string of a token run: each token's phonemes, a blank where the token is followed by white space, ends trimmed."""
+    return "".join(f"{t.phonemes} " if t.whitespace else t.phonemes for t in tokens).strip()
+
+
+def _cut_index(tokens, projected: int, tiers=SPLIT_TIERS, closers=CLOSERS, limit: int = PHONEME_LIMIT) -> int:
+    """How many leading tokens to emit when the run plus the incoming token would hold `projected` phonemes: cut behind the LAST mark of the
+    best tier whose remainder (projected minus what is emitted) fits the limit; no usable mark -> emit everything."""
+    n = len(tokens)
+    for tier in tiers:
+        marks = frozenset(tier)
+        last = max((i for i in range(n) if tokens[i].phonemes in marks), default=-1)
+        if last < 0:
+            continue
+        cut = last + 1
+        if cut < n and tokens[cut].phonemes in closers:
+            cut += 1
+        if projected - len(_phoneme_text(tokens[:cut])) <= limit:
+            return cut
+    return n
+
+
+def plan_chunks(tokens, limit: int = PHONEME_LIMIT):
+    """Cuts a G2P token stream into runs of at most `limit` phonemes (what one forward accepts), preferring sentence boundaries.
+    A token's phonemes are normalised on the way (None -> "", the American flap written as T).  Yields lists of tokens."""
+    run, held = [], 0  # `held`: phonemes in `run`, counting the blank behind every token but the stripped ends after a cut
+    for tok in tokens:
+        tok.phonemes = (tok.phonemes or "").replace("ɾ", "T")
+        piece = f"{tok.phonemes} " if tok.whitespace else tok.phonemes
+        projected = held + len(piece.rstrip())
+        if projected > limit:
+            cut = _cut_index(run, projected, limit=limit)
+            yield run[:cut]
+            run = run[cut:]
+            held = len(_phoneme_text(run))
+            if not run:
+                piece = piece.lstrip()
+        run.append(tok)
+        held += len(piece)
+    if run:
+        yield run
+
+
 class KokoroPipeline:
     """pipeline.py:45-460.  model=False gives a "quiet" pipeline that only phonemises / chunks."""
 
@@ -101,45 +152,23 @@ class KokoroPipeline:
         self.voices[voice] = np.mean(np.stack(packs), axis=0)
         return self.voices[voice]
 
-    # ---- chunking on duck-typed tokens (.phonemes, .whitespace, .text) (pipeline.py:163-226) -------------------
+    # ---- chunk planning on duck-typed tokens (.text, .phonemes, .whitespace); behaviour of pipeline.py:163-226, pinned by
+    # tests/golden/chunker_cases.json -----------------------------------------------------------------------------------------
     @classmethod
     def tokens_to_ps(cls, tokens) -> str:
-        return "".join(t.phonemes + (" " if t.whitespace else "") for t in tokens).strip()
+        return _phoneme_text(tokens)
 
     @classmethod
     def tokens_to_text(cls, tokens) -> str:
-        return "".join(t.text + t.whitespace for t in tokens).strip()
+        return "".join(f"{t.text}{t.whitespace}" for t in tokens).strip()
 
     @classmethod
-    def waterfall_last(cls, tokens, next_count: int, waterfall=("!.?…", ":;", ",—"), bumps=(")", "”")) -> int:
-        for w in waterfall:
-            z = next((i for i, t in reversed(list(enumerate(tokens))) if t.phonemes in set(w)), None)
-            if z is None:
-                continue
-            z += 1
-            if z < len(tokens) and tokens[z].phonemes in bumps:
-                z += 1
-            if next_count - len(cls.tokens_to_ps(tokens[:z])) <= 510:
-                return z
-        return len(tokens)
+    def waterfall_last(cls, tokens, next_count: int, waterfall=SPLIT_TIERS, bumps=CLOSERS) -> int:
+        return _cut_index(tokens, next_count, waterfall, bumps)
 
     def en_tokenize(self, tokens) -> Generator[Tuple[str, str, list], None, None]:
-        tks, pcount = [], 0
-        for t in tokens:
-            t.phonemes = "" if t.phonemes is None else t.phonemes.replace("ɾ", "T")
-            next_ps = t.phonemes + (" " if t.whitespace else "")
-            next_pcount = pcount + len(next_ps.rstrip())
-            if next_pcount > 510:
-                z = KokoroPipeline.waterfall_last(tks, next_pcount)
-                yield KokoroPipeline.tokens_to_text(tks[:z]), KokoroPipeline.tokens_to_ps(tks[:z]), tks[:z]
-                tks = tks[z:]
-                pcount = len(KokoroPipeline.tokens_to_ps(tks))
-                if not tks:
-                    next_ps = next_ps.lstrip()
-            tks.append(t)
-            pcount += len(next_ps)
-        if tks:
-            yield KokoroPipeline.tokens_to_text(tks), KokoroPipeline.tokens_to_ps(tks), tks
+        for part in plan_chunks(tokens):
+            yield KokoroPipeline.tokens_to_text(part), _phoneme_text(part), part
 
     # ---- inference ---------------------------------------------------------------------------------------
     @classmethod
@@ -171,33 +200,37 @@ class KokoroPipeline:
 
     @classmethod
     def join_timestamps(cls, tokens, pred_dur) -> None:
-        """pipeline.py:292-328: half-frame bookkeeping, 80 half-frames per second."""
-        MAGIC_DIVISOR = 80
-        pd = [int(v) for v in (pred_dur.tolist() if hasattr(pred_dur, "tolist") else pred_dur)]
-        if not tokens or len(pd) < 3:
+        """Word-level start_ts / end_ts from the per-phoneme durations (behaviour of pipeline.py:292-328, pinned by
+        tests/golden/chunker_cases.json).  Time is kept in HALF frames (a frame is 1/40 s, so 80 per second) so that the pause a
+        space character stands for can be split evenly between the word before and the word after it."""
+        frames = [int(v) for v in (pred_dur.tolist() if hasattr(pred_dur, "tolist") else pred_dur)]
+        if not tokens or len(frames) < 3:  # <bos>, at least one phoneme, <eos>
             return
-        left = right = 2 * max(0, pd[0] - 3)
-        i = 1
-        for t in tokens:
-            if i >= len(pd) - 1:
-                break
-            if not t.phonemes:
-                if t.whitespace:
-                    i += 1
-                    left = right + pd[i]
-                    right = left + pd[i]
-                    i += 1
+        eos = len(frames) - 1
+        # `opened`: where the next word starts; `closed`: where the previous word's share of the following pause ends
+        opened = closed = 2 * max(0, frames[0] - 3)
+        at = 1  # index of the next unconsumed duration
+        for tok in tokens:
+            if at >= eos:
+                return
+            width = len(tok.phonemes) if tok.phonemes else 0
+            if width == 0:
+                if tok.whitespace:  # a token that is only a pause: the duration AFTER the current one is charged twice, two entries are consumed
+                    pause = frames[at + 1]
+                    opened = closed + pause
+                    closed = opened + pause
+                    at += 2
                 continue
-            j = i + len(t.phonemes)
-            if j >= len(pd):
-                break
-            t.start_ts = left / MAGIC_DIVISOR
-            token_dur = sum(pd[i:j])
-            space_dur = pd[j] if t.whitespace else 0
-            left = right + (2 * token_dur) + space_dur
-            t.end_ts = left / MAGIC_DIVISOR
-            right = left + space_dur
-            i = j + (1 if t.whitespace else 0)
+            nxt = at + width
+            if nxt > eos:
+                return
+            spoken = sum(frames[at:nxt])
+            pause = frames[nxt] if tok.whitespace else 0
+            tok.start_ts = opened / HALF_FRAMES_PER_SECOND
+            opened = closed + 2 * spoken + pause
+            tok.end_ts = opened / HALF_FRAMES_PER_SECOND
+            closed = opened + pause
+            at = nxt + (1 if tok.whitespace else 0)
 
     @dataclass
     class Result:

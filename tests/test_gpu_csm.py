@@ -151,6 +151,39 @@ def test_csm_graph_replay_gives_the_same_codes():
     np.testing.assert_array_equal(run(True), run(False))
 
 
+def test_csm_setup_caches_twice_in_graph_mode_drops_the_stale_graphs():
+    """setup_caches frees and re-allocates the KV caches; a frame-step graph captured before it has the old pointers baked in and must
+    not be replayed (use after free).  Graph mode: setup, a few frames, setup AGAIN (same and larger batch), frames equal to the eager run."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_tiny_config()
+    w = P.csm_synth_checkpoint(cfg, 4)
+    rng = np.random.default_rng(18)
+    B, n = 2, cfg["audio_num_codebooks"]
+    tok, msk = _prompt(cfg, rng, B, 4, 2)
+
+    def frames(model, k):
+        out = [model.generate_frame(torch.tensor(tok), torch.tensor(msk)).cpu().numpy().copy()]
+        for _ in range(k):
+            t_in = np.zeros((B, 1, n + 1), np.int64)
+            t_in[:, 0, :n] = out[-1]
+            m_in = np.zeros((B, 1, n + 1), np.float32)
+            m_in[:, 0, :n] = 1
+            out.append(model.generate_frame(torch.tensor(t_in), torch.tensor(m_in)).cpu().numpy().copy())
+        return np.stack(out)
+
+    eager = SesameModel(cfg, w)
+    eager.setup_caches(B)
+    ref = frames(eager, 5)
+    model = SesameModel(cfg, w)
+    model.set_graph_mode(True)
+    for mb in (B, B, B + 3):  # the second and third setup free the caches the first graphs were captured on
+        model.setup_caches(mb)
+        junk = torch.full((1 << 22,), 7.0, device="cuda")  # re-use the freed blocks for something else
+        np.testing.assert_array_equal(frames(model, 5), ref)
+        del junk
+
+
 def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     """llama-1B / llama-100M head geometry (32 q / 8 kv heads of 64; 8 q / 2 kv heads of 128) with 2 layers each and small vocabularies."""
     from mlx_audio_amd.csm import SesameModel

@@ -215,3 +215,20 @@ def test_batch_scheduler_plans_and_keeps_text_order():
     assert sorted(map(sorted, calls)) == sorted(map(sorted, [["a" * 300], ["a" * 31, "a" * 30, "a" * 29], ["a" * 8, "a" * 7]]))
     calls.clear()
     assert [r.phonemes for r in p("\n".join(words), voice="v")] == words and all(len(c) == 1 for c in calls)  # default: chunk by chunk
+
+
+def test_chunk_planner_and_timestamps_against_golden_vectors():
+    """tests/golden/chunker_cases.json (made by tests/golden/make_golden_chunker.py): 36 random token streams -> the chunks of
+    pipeline.py:170-226, 42 (tokens, pred_dur) pairs -> the start / end times of pipeline.py:292-328, incl. too-short duration vectors."""
+    from types import SimpleNamespace
+
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "chunker_cases.json")))
+    p = KokoroPipeline(lang_code="a", model=False, repo_id="m")
+    for c in cases["chunk_cases"]:
+        objs = [SimpleNamespace(text=t, phonemes=ph, whitespace=ws) for t, ph, ws in c["tokens"]]
+        got = [[gs, ps, len(tk)] for gs, ps, tk in p.en_tokenize(objs)]
+        assert got == c["chunks"]  # (the reference's planner can overshoot 510 when the blanks it did not count add up; its callers truncate)
+    for c in cases["timestamp_cases"]:
+        objs = [SimpleNamespace(text=t, phonemes=ph, whitespace=ws, start_ts=None, end_ts=None) for t, ph, ws in c["tokens"]]
+        KokoroPipeline.join_timestamps(objs, np.asarray(c["pred_dur"], np.int32))
+        assert [[o.start_ts, o.end_ts] for o in objs] == c["ts"]
