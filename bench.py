@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--quantized", action="store_true",
                     help="BASELINE config 5: the checkpoint goes through the MLX 8-bit group quantisation (group 64) of the reference's predicate and "
                          "its linears run on the fp8 matrix instruction; use with --batch 64.  The default run is config 2 (the headline).")
+    ap.add_argument("--quantization-kernel", default="exact", choices=["exact", "mxfp8"],
+                    help="with --quantized: 'exact' (default) = the dequantised weights scale*q+bias on the bf16 MFMA kernels, the reference's arithmetic "
+                         "(tts/utils.py:241-260); 'mxfp8' = the opt-in e4m3 kernels.  The other one is measured too and reported next to `value`.")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU (gloo): rendezvous, barrier, MAX reduction, rank 0's line")
     args = ap.parse_args()
@@ -135,13 +138,35 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
+    out = bench_kokoro(args, rank, world)
+    if args.quantized:  # (every rank: the second configuration has the same collectives)
+        # config 5 reports BOTH arithmetic choices for the quantised layer set: the default ("exact": dequantised weights, bf16 activations -- the
+        # reference's semantics) is `value`; the opt-in fp8 kernels (or vice versa with --quantization-kernel mxfp8) ride along
+        other = "mxfp8" if args.quantization_kernel == "exact" else "exact"
+        alt = bench_kokoro(args, rank, world, quantization_kernel=other, brief=True)
+        out["quantization_kernel"] = args.quantization_kernel
+        out["other_quantization_kernel"] = {"kernel": other, "value": alt["value"], "ms_per_step": alt["ms_per_step"],
+                                            "note": "mxfp8 = e4m3 weights AND activations on v_mfma_scale_f32_32x32x64_f8f6f4 (opt-in, narrower than the reference's arithmetic)"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist_mod.destroy_process_group()
+
+
+def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
+    """One configuration of the Kokoro forward: builds the engine, times K steps, (unless brief) brackets the kernels and measures the B = 1
+    latency and the CPU baseline.  Returns the JSON object (rank 0; other ranks return a stub)."""
+    quantization_kernel = quantization_kernel or args.quantization_kernel
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import mlx_audio_amd.params as P
     from mlx_audio_amd import _lib
@@ -156,13 +181,14 @@ def main():
             raise SystemExit("--quantized is the bf16 + fp8 configuration")
         from mlx_audio_amd.quant import dequantize_checkpoint, quantize_checkpoint
 
-        quantization = {"group_size": 64, "bits": 8}
+        quantization = {"group_size": 64, "bits": 8} if quantization_kernel == "mxfp8" else None
         w = dequantize_checkpoint(quantize_checkpoint(w, 64, 8), 64, 8)  # what load_model hands the engine for an 8-bit checkpoint
+        w = {k: torch.tensor(np.asarray(v, np.float32)).to(torch.bfloat16) for k, v in w.items()}  # an 8-bit checkpoint of the bf16 model
     if args.dtype == "bfloat16" and not args.quantized:
         w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
     eng = KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization)
     if args.quantized:
-        assert eng.lib.kk_quantized_layers(eng._h) == 6
+        assert eng.lib.kk_quantized_layers(eng._h) == (6 if quantization_kernel == "mxfp8" else 0)
     dev = eng.device
 
     # ---- synthetic workload: global batch = world * B utterances, this rank takes its contiguous shard
@@ -224,7 +250,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, dt_prof = None, None
-    if not args.no_profile:
+    if not args.no_profile and not brief:
         eng.profile_begin()  # forwards with an open profile run eagerly
         barrier()
         t1 = time.perf_counter()
@@ -236,7 +262,7 @@ def main():
 
     # p50 per-utterance latency (second half of BASELINE.json's metric): B = 1, same shapes, after the timed region
     p50_ms = None
-    if rank == 0 and not args.no_latency:
+    if rank == 0 and not args.no_latency and not brief:
         i1, l1, T1 = eng.pack_ids(utts[:1])
         r1, s1, f1 = ref_s[:1].contiguous(), speed[:1].contiguous(), forced[:1].contiguous()
         w1 = torch.empty((1, 600 * Fmax), dtype=torch.float32, device=dev)
@@ -254,7 +280,8 @@ def main():
         dt = float(t.item())
 
     audio_s = Bglob * (600 * Fmax) / SR * args.steps
-    dtype_tag = ("bf16+fp8(e4m3, quantised linears)" if args.quantized else "bf16") if args.dtype == "bfloat16" else "f32"
+    dtype_tag = ("bf16" if not args.quantized else ("bf16+fp8(e4m3, quantised linears)" if quantization_kernel == "mxfp8" else
+                 "bf16 (8-bit affine weights dequantised: scale*q+bias)")) if args.dtype == "bfloat16" else "f32"
     out = {
         "metric": f"audio-sec/sec (xRT), Kokoro-82M{' 8-bit quantised' if args.quantized else ''} batch={B} fixed 128-phoneme utterances per GPU",
         "value": audio_s / dt,
@@ -279,7 +306,7 @@ def main():
         pmc = None
         try:
             # PMC byte counts were taken at one batch size per configuration: B = 32 for the bf16 / fp32 entries, B = 64 for config 5
-            key, pmc_batch = ("bfloat16+fp8 (config 5, B=64, r01_i)", 64) if args.quantized else (args.dtype, 32)
+            key, pmc_batch = ("bfloat16+fp8 (config 5, B=64, r01_i)", 64) if (args.quantized and quantization_kernel == "mxfp8") else (args.dtype, 32)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(key) if B == pmc_batch else None
         except Exception:
             pmc = None
@@ -316,11 +343,11 @@ def main():
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
             out["kernel_ms_per_step"]["_sum_bracketed"] = round(tot / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not brief:
             out["cpu_baseline"] = cpu_baseline(cfg, P.synth_checkpoint(cfg, 0), utts[0], ref_np[0:1])
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -2,13 +2,15 @@
 `nn.quantize(model, group_size, bits, class_predicate)` turns a Linear / Embedding weight [O, I] into
     weight  uint32 [O, I * bits / 32]   (32 / bits values per word, element j of a word in bits [j*bits, (j+1)*bits), least significant first)
     scales  [O, I / group_size],  biases [O, I / group_size]              w ~= scales * q + biases  per group of `group_size` inputs
-This module dequantises such triplets at LOAD time; the arithmetic then runs on the bf16 MFMA path with exactly the weights MLX's
-`quantized_matmul` multiplies by.  The packing layout is upstream-MLX knowledge (MLX is not in the reference tree): PARITY UNPINNED.
-In bf16 mode an 8-bit checkpoint's Linear set then runs on the block-scaled fp8 matrix instruction: the engine re-quantises the
-dequantised matrices to e4m3 with one power-of-two scale per group (kk_set_quantization, csrc/kk_mxfp8.hip)."""
+This module dequantises such triplets at LOAD time; the arithmetic then runs on the ordinary kernels (bf16 MFMA in bf16 mode) with exactly
+the weights MLX's `quantized_matmul` multiplies by and bf16 activations -- the reference's arithmetic, and the DEFAULT for such a checkpoint.
+The packing layout is upstream-MLX knowledge (MLX is not in the reference tree): PARITY UNPINNED.
+Opt-in (`load_model(..., quantization_kernel="mxfp8")`): the 8-bit checkpoint's Linear set runs on the block-scaled fp8 matrix instruction,
+the engine re-quantising the dequantised matrices to e4m3 with one power-of-two scale per group (kk_set_quantization, csrc/kk_mxfp8.hip;
+SURVEY 8 row Q1) -- faster on those layers, but narrower arithmetic than the reference's (4 significant bits for weights AND activations)."""
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -45,17 +47,21 @@ def dequantize_affine(words: np.ndarray, scales: np.ndarray, biases: np.ndarray,
     return q * s + b
 
 
-def dequantize_checkpoint(weights: Dict[str, np.ndarray], group_size: int, bits: int) -> Dict[str, np.ndarray]:
+def dequantize_checkpoint(weights: Dict[str, np.ndarray], group_size: int, bits: int, per_layer: Optional[dict] = None) -> Dict[str, np.ndarray]:
     """Every `{p}.weight` that comes with `{p}.scales` and `{p}.biases` (the reference's predicate, utils.py:243-252) is replaced by its
-    dequantised float32 matrix; the scale / bias tensors are dropped; everything else passes through."""
+    dequantised float32 matrix; the scale / bias tensors are dropped; everything else passes through.  `per_layer` is the rest of
+    config["quantization"]: a layer path mapped to its own {"group_size", "bits"} (the "custom per layer quantizations" of utils.py:244-246)
+    is dequantised with THOSE parameters; a path mapped to False was never quantised and passes through."""
+    per_layer = per_layer or {}
     out = {}
     for k, v in weights.items():
         if k.endswith(".scales") or k.endswith(".biases"):
             continue
         p = k[: -len(".weight")] if k.endswith(".weight") else None
-        if p is not None and f"{p}.scales" in weights and f"{p}.biases" in weights:
-            out[k] = dequantize_affine(np.asarray(v), np.asarray(weights[f"{p}.scales"], np.float32), np.asarray(weights[f"{p}.biases"], np.float32),
-                                       group_size, bits)
+        own = per_layer.get(p) if p is not None else None
+        if p is not None and own is not False and f"{p}.scales" in weights and f"{p}.biases" in weights:
+            g, nb = (int(own.get("group_size", group_size)), int(own.get("bits", bits))) if isinstance(own, dict) else (group_size, bits)
+            out[k] = dequantize_affine(np.asarray(v), np.asarray(weights[f"{p}.scales"], np.float32), np.asarray(weights[f"{p}.biases"], np.float32), g, nb)
         else:
             out[k] = v
     return out

@@ -48,9 +48,14 @@ def get_model_and_args(model_type: str, model_name):
     return kokoro, model_type
 
 
-def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtype: str = None, **kwargs):
+def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtype: str = None, quantization_kernel: str = "exact", **kwargs):
     """Returns a ready `kokoro.Model` (weights folded, packed and resident in HBM).
-    Raises FileNotFoundError when no safetensors are found, ValueError for an unsupported model type."""
+    Raises FileNotFoundError when no safetensors are found, ValueError for an unsupported model type.
+    quantization_kernel (only matters for a checkpoint with config["quantization"]): "exact" (default) multiplies by the dequantised
+    weights `scale * q + bias` with the mode's ordinary kernels, i.e. the reference's arithmetic (tts/utils.py:241-260); "mxfp8" is the
+    opt-in that re-quantises an 8-bit checkpoint's linears to e4m3 and runs them on the block-scaled fp8 matrix instruction."""
+    if quantization_kernel not in ("exact", "mxfp8"):
+        raise ValueError(f"quantization_kernel must be 'exact' or 'mxfp8', not {quantization_kernel!r}")
     if isinstance(model_path, str):
         model_name = model_path.lower().rstrip("/").split("/")[-1].split("-")
         path = get_model_path(model_path)
@@ -88,12 +93,16 @@ def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtyp
 
         as_np = {k: (v.float().numpy() if isinstance(v, torch.Tensor) and v.dtype in (torch.bfloat16, torch.float16) else
                      (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))) for k, v in weights.items()}
-        weights = dequantize_checkpoint(as_np, int(quantization["group_size"]), int(quantization["bits"]))
+        per_layer = {k: v for k, v in quantization.items() if k not in ("group_size", "bits")}  # custom per layer quantizations (utils.py:244-246)
+        weights = dequantize_checkpoint(as_np, int(quantization["group_size"]), int(quantization["bits"]), per_layer)
     cfg = arch.ModelConfig.from_dict(config)
-    # an 8-bit checkpoint in bf16 mode runs its quantised linears on the fp8 matrix instruction (kk_set_quantization); other bit
-    # widths (and the fp32 parity mode) use the dequantised weights on the ordinary kernels
-    q8 = quantization if (quantization is not None and int(quantization["bits"]) == 8 and int(quantization["group_size"]) % 32 == 0
-                          and compute_dtype == "bfloat16") else None
+    # default: the dequantised weights on the ordinary kernels -- what the reference computes.  Opt-in "mxfp8": an 8-bit checkpoint in
+    # bf16 mode runs its quantised linears on the fp8 matrix instruction (kk_set_quantization)
+    q8 = None
+    if quantization_kernel == "mxfp8":
+        if quantization is None or int(quantization["bits"]) != 8 or int(quantization["group_size"]) % 32 != 0 or compute_dtype != "bfloat16":
+            raise ValueError("quantization_kernel='mxfp8' needs an 8-bit checkpoint (group size a multiple of 32) in bfloat16 mode")
+        q8 = {"group_size": int(quantization["group_size"]), "bits": 8}
     model = arch.Model(cfg, compute_dtype=compute_dtype, quantization=q8)
     model.load_weights(weights, strict=strict)
     return model

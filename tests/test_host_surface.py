@@ -232,3 +232,24 @@ def test_chunk_planner_and_timestamps_against_golden_vectors():
         objs = [SimpleNamespace(text=t, phonemes=ph, whitespace=ws, start_ts=None, end_ts=None) for t, ph, ws in c["tokens"]]
         KokoroPipeline.join_timestamps(objs, np.asarray(c["pred_dur"], np.int32))
         assert [[o.start_ts, o.end_ts] for o in objs] == c["ts"]
+
+
+def test_dequantize_checkpoint_honours_per_layer_group_size_and_bits():
+    """config["quantization"][p] = {"group_size", "bits"} (tts/utils.py:244-246): that layer's triplet is unpacked with ITS parameters, the
+    rest with the global ones; a layer mapped to False passes through untouched."""
+    from mlx_audio_amd.quant import dequantize_affine, dequantize_checkpoint, quantize_affine
+
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.standard_normal(s).astype(np.float32) for s in ((8, 128), (16, 64), (4, 64)))
+    ck = {}
+    ck["x.weight"], ck["x.scales"], ck["x.biases"] = quantize_affine(a, 64, 8)
+    ck["y.weight"], ck["y.scales"], ck["y.biases"] = quantize_affine(b, 32, 4)
+    ck["z.weight"] = c
+    ck["norm.weight"] = np.ones(7, np.float32)
+    out = dequantize_checkpoint(ck, 64, 8, {"y": {"group_size": 32, "bits": 4}, "z": False})
+    assert sorted(out) == ["norm.weight", "x.weight", "y.weight", "z.weight"]
+    np.testing.assert_array_equal(out["x.weight"], dequantize_affine(ck["x.weight"], ck["x.scales"], ck["x.biases"], 64, 8))
+    np.testing.assert_array_equal(out["y.weight"], dequantize_affine(ck["y.weight"], ck["y.scales"], ck["y.biases"], 32, 4))
+    assert out["y.weight"].shape == (16, 64) and np.abs(out["y.weight"] - b).max() < (b.max() - b.min()) / 15
+    assert np.abs(out["x.weight"] - a).max() < (a.max() - a.min()) / 255
+    assert out["z.weight"] is c
