@@ -172,14 +172,21 @@ class KokoroEngine:
               "kk_forward_text")
         return pred
 
-    def forward_audio(self, B, Tmax, lens, ref_s, dur, Fmax, noise_mode=_lib.NOISE_PHILOX, sine_noise=None, seed=0):
-        # NB: the workspace must be the one kk_forward_text just used (same B, Tmax) and large enough for Fmax
+    def forward_audio(self, B, Tmax, lens, ref_s, dur, Fmax, noise_mode=_lib.NOISE_PHILOX, sine_noise=None, seed=0, out=None):
+        # the workspace must be the one kk_forward_text just used (same B, Tmax).  The text stage's results live in its first
+        # kk_workspace_bytes(B, Tmax, 0) bytes at offsets that do not depend on Fmax (bump allocation in a fixed order), so a workspace that
+        # is too small for this Fmax -- the caller only learns Fmax from the predicted durations -- is re-allocated and that prefix copied
         need = int(self.lib.kk_workspace_bytes(self._h, B, Tmax, Fmax))
-        if self._ws is None or self._ws.numel() < need:
-            raise _lib.KokoroHipError("forward_audio: call workspace(B, Tmax, Fmax_bound) before forward_text so the text stage's results survive")
+        if self._ws is None:
+            raise _lib.KokoroHipError("forward_audio: run forward_text first (its results live in the workspace)")
+        if self._ws.numel() < need:
+            keep = min(int(self.lib.kk_workspace_bytes(self._h, B, Tmax, 0)), self._ws.numel())
+            grown = torch.empty(need, dtype=torch.uint8, device=self.device)
+            grown[:keep].copy_(self._ws[:keep])
+            self._ws = grown
         ws = self._ws
         self._last_B = B
-        wav = torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
+        wav = out if out is not None else torch.empty((B, self.upsample * Fmax), dtype=torch.float32, device=self.device)
         nfr = torch.empty((B,), dtype=torch.int32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         check(

@@ -102,8 +102,11 @@ class Model:
         assert len(ids) + 2 <= self.context_length, (len(ids) + 2, self.context_length)  # kokoro.py:131-134
         return ids
 
-    def batch_call(self, phonemes: Sequence[str], ref_s, speed: Union[Number, Sequence[Number]] = 1, seed: Optional[int] = None):
-        """B utterances in one padded batch.  ref_s [B, 256].  Returns a list of Output (audio [1, 600*F_b])."""
+    def batch_call(self, phonemes: Sequence[str], ref_s, speed: Union[Number, Sequence[Number]] = 1, seed: Optional[int] = None,
+                   noise_mode: int = _lib.NOISE_PHILOX):
+        """B utterances in one padded batch.  ref_s [B, 256]; speed one number or one per utterance.  Returns a list of Output
+        (audio [1, 600*F_b]).  The text stage runs ONCE: kk_forward_text, the reference's host sync on the durations (kokoro.py:151-153),
+        then kk_forward_audio on the text stage's results in the workspace."""
         eng = self.engine
         dev = eng.device
         B = len(phonemes)
@@ -113,19 +116,14 @@ class Model:
         if seed is None:
             self._seed += 1
             seed = self._seed
-        # the reference's host sync (kokoro.py:151-153): durations decide the output length
-        bound = max(1, int(self.config.max_dur / float(sp.min().item()) + 1)) * Tmax
-        eng.workspace(B, Tmax, 1)  # text stage only; re-sized below once F is known
+        eng.workspace(B, Tmax, 0)
         pred = eng.forward_text(ids, lens, ref, sp)
-        F = pred.sum(dim=1)
-        Fmax = int(F.max().item())
-        assert 0 < Fmax <= bound
-        wav, pred2, nfr = eng.forward(ids, lens, ref, sp, Fmax, forced_dur=pred, noise_mode=_lib.NOISE_PHILOX, seed=seed)
-        out = []
-        for b in range(B):
-            T = int(lens[b].item())
-            out.append(self.Output(audio=wav[b : b + 1, : 600 * int(F[b].item())], pred_dur=pred[b, :T]))
-        return out
+        F = pred.sum(dim=1).cpu()  # the host sync: durations decide the output length
+        Fmax = int(F.max())
+        assert 0 < Fmax <= max(1, int(self.config.max_dur / float(sp.min().item()) + 1)) * Tmax
+        wav, nfr = eng.forward_audio(B, Tmax, lens, ref, pred, Fmax, noise_mode=noise_mode, seed=seed)
+        Ts = lens.cpu().tolist()
+        return [self.Output(audio=wav[b : b + 1, : 600 * int(F[b])], pred_dur=pred[b, : Ts[b]]) for b in range(B)]
 
     def __call__(self, phonemes: str, ref_s, speed: Number = 1, return_output: bool = False, decoder=None):
         o = self.batch_call([phonemes], ref_s, speed)[0]

@@ -1,0 +1,214 @@
+"""Request-batching serving entry: the `/tts` handler's semantics (mlx_audio/server.py:107-318) without the HTTP layer, with the
+one thing the reference's handler cannot do -- chunks of CONCURRENT requests share padded batches.
+
+The reference serves one request at a time: `tts_model.generate(**gen_params)` (server.py:270) walks the request's chunks batch-1 and the
+handler concatenates the segments (server.py:277-288).  Here `TTSService.submit()` returns a future at once; a worker thread drains the
+queue, phonemises and chunks every waiting request with the request's own pipeline (KokoroPipeline._chunks: the reference's chunking),
+pools ALL their chunks, cuts the pool into length-sorted padded batches (KokoroPipeline.plan_batches) and runs one kk_forward_text +
+kk_forward_audio per batch (Model.batch_call); each request's segments are put back in text order and concatenated.  A chunk's result
+does not depend on its batch neighbours (bit-identical to batch 1 up to the Philox noise stream), so batching is invisible to callers.
+
+Parameter semantics follow the handler: empty text -> 400 "Text is empty"; `speed` is a string parsed as float in [0.5, 2.0] (400
+otherwise); `language` names / codes map to a lang_code with the fallback `voice[0]` (server.py:193-220); `voice` None -> the model's
+default voice.  Errors are delivered as `TTSError(status, message)` on the future -- what the handler returns as JSON + status code."""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from concurrent.futures import Future
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+LANGUAGE_CODES = {"american_english": "a", "british_english": "b", "spanish": "e", "french": "f", "hindi": "h", "italian": "i", "portuguese": "p",
+                  "japanese": "j", "mandarin_chinese": "z"}
+LANGUAGE_CODES.update({c: c for c in "abefhipjz"})
+
+
+class TTSError(Exception):
+    """What the handler answers with `JSONResponse({"error": message}, status_code=status)`."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status, self.message = status, message
+
+
+@dataclass
+class TTSResponse:
+    audio: np.ndarray          # float32 [samples]: the request's segments concatenated (server.py:288)
+    sample_rate: int
+    segments: int
+    phonemes: List[str]
+    batches: List[int] = field(default_factory=list)  # ids of the device batches this request's chunks rode in (diagnostics)
+
+
+@dataclass
+class _Request:
+    text: str
+    voice: str
+    speed: float
+    lang_code: str
+    future: Future
+    chunks: List[Tuple[str, str]] = field(default_factory=list)  # (graphemes, phonemes) in text order
+
+
+def parse_request(text: str, voice: Optional[str] = None, speed: str = "1.0", language: str = "a", default_voice: str = "af_heart"):
+    """The handler's validation and mapping (server.py:126-163, 193-220) -> (text, voice, speed_value, lang_code); raises TTSError."""
+    if not text or not text.strip():
+        raise TTSError(400, "Text is empty")
+    try:
+        value = float(speed)
+    except (TypeError, ValueError):
+        raise TTSError(400, "Invalid speed value") from None
+    if value < 0.5 or value > 2.0:
+        raise TTSError(400, "Speed must be between 0.5 and 2.0")
+    has_voice = bool(voice and voice.strip())
+    lang_code = LANGUAGE_CODES.get(str(language).lower(), voice[0] if has_voice else "a")
+    return text, (voice if has_voice else default_voice), value, lang_code
+
+
+def plan_pool(lengths: List[int], max_batch: int, max_pad: float = 0.25) -> List[List[int]]:
+    """Batches over the pooled chunks of every waiting request: KokoroPipeline.plan_batches (length-sorted, at most `max_batch` per batch,
+    padding waste bounded by `max_pad`).  Indices refer to the pool."""
+    from .pipeline import KokoroPipeline
+
+    return KokoroPipeline.plan_batches(lengths, max_batch, max_pad)
+
+
+class TTSService:
+    def __init__(self, model, max_batch: int = 32, max_wait_ms: float = 4.0, g2p: Optional[Callable] = None, noise_mode: Optional[int] = None,
+                 repo_id: Optional[str] = None, start: bool = True):
+        """model: a loaded kokoro.Model.  max_batch: utterances per device batch.  max_wait_ms: how long the worker waits for more
+        requests after the first one of a round (the batching window).  g2p: passed to the pipelines (tests / phoneme input)."""
+        from . import _lib
+
+        self.model = model
+        self.max_batch = int(max_batch)
+        self.max_wait = float(max_wait_ms) / 1e3
+        self.noise_mode = _lib.NOISE_PHILOX if noise_mode is None else int(noise_mode)
+        self._g2p = g2p
+        self._repo_id = repo_id or getattr(model, "repo_id", None) or getattr(model, "REPO_ID", "local")
+        self._pipes: Dict[str, object] = {}
+        self._q: "queue.Queue[Optional[_Request]]" = queue.Queue()
+        self._batch_id = 0
+        self.stats = {"requests": 0, "chunks": 0, "batches": 0, "rounds": 0}
+        self._thread = None
+        if start:
+            self.start()
+
+    # ---- life cycle
+    def start(self):
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._worker, name="tts-service", daemon=True)
+            self._thread.start()
+
+    def close(self):
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join()
+            self._thread = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- the handler's entry
+    def submit(self, text: str, voice: Optional[str] = None, speed: str = "1.0", language: str = "a", **_ignored) -> Future:
+        fut: Future = Future()
+        try:
+            text, voice, value, lang = parse_request(text, voice, speed, language)
+        except TTSError as e:
+            fut.set_exception(e)
+            return fut
+        self._q.put(_Request(text=text, voice=voice, speed=value, lang_code=lang, future=fut))
+        return fut
+
+    def tts(self, text: str, **kw) -> TTSResponse:
+        """Blocking form of one request (what a handler thread would call)."""
+        return self.submit(text, **kw).result()
+
+    # ---- worker
+    def _pipeline(self, lang_code: str):
+        from .pipeline import KokoroPipeline
+
+        if lang_code not in self._pipes:
+            self._pipes[lang_code] = KokoroPipeline(lang_code=lang_code, model=self.model, repo_id=self._repo_id, g2p=self._g2p)
+        return self._pipes[lang_code]
+
+    def _collect(self) -> Optional[List[_Request]]:
+        first = self._q.get()
+        if first is None:
+            return None
+        reqs, deadline = [first], time.monotonic() + self.max_wait
+        while True:
+            left = deadline - time.monotonic()
+            try:
+                r = self._q.get(timeout=max(left, 0.0)) if left > 0 else self._q.get_nowait()
+            except queue.Empty:
+                return reqs
+            if r is None:
+                self._q.put(None)  # finish this round, then stop
+                return reqs
+            reqs.append(r)
+
+    def run_round(self, reqs: List[_Request]) -> None:
+        """One batching round over `reqs`: chunk, pool, batch, synthesise, hand back.  (Public for tests: a deterministic round.)"""
+        import torch
+
+        pool = []  # (request index, position in request, phonemes, style row, speed)
+        live = []
+        for ri, r in enumerate(reqs):
+            try:
+                pipe = self._pipeline(r.lang_code)
+                if pipe.g2p is None:
+                    raise TTSError(500, "no G2P available for text input (misaki is not installed); pass g2p= to TTSService")
+                pack = pipe.load_voice(r.voice)
+                r.chunks = [(gs, ps) for _, gs, ps, _ in pipe._chunks(r.text, r"\n+")]
+                if not r.chunks:
+                    raise TTSError(500, "No audio generated")
+                for ci, (_, ps) in enumerate(r.chunks):
+                    pool.append((ri, ci, ps, np.asarray(pack[len(ps) - 1], np.float32).reshape(256), r.speed))
+                live.append(ri)
+            except TTSError as e:
+                r.future.set_exception(e)
+            except Exception as e:  # noqa: BLE001  (the handler answers 500 with the message)
+                r.future.set_exception(TTSError(500, f"Failed to generate: {e}"))
+        outs: Dict[Tuple[int, int], np.ndarray] = {}
+        rode: Dict[int, List[int]] = {ri: [] for ri in live}
+        failed: Dict[int, Exception] = {}
+        for idx in plan_pool([len(p[2]) for p in pool], self.max_batch):
+            self._batch_id += 1
+            try:
+                res = self.model.batch_call([pool[i][2] for i in idx], np.stack([pool[i][3] for i in idx]), [pool[i][4] for i in idx],
+                                            noise_mode=self.noise_mode)
+                torch.cuda.synchronize()
+                for i, o in zip(idx, res):
+                    outs[(pool[i][0], pool[i][1])] = o.audio[0].detach().float().cpu().numpy()
+                    if self._batch_id not in rode[pool[i][0]]:
+                        rode[pool[i][0]].append(self._batch_id)
+            except Exception as e:  # noqa: BLE001
+                for i in idx:
+                    failed[pool[i][0]] = e
+            self.stats["batches"] += 1
+        for ri in live:
+            r = reqs[ri]
+            if ri in failed:
+                r.future.set_exception(TTSError(500, f"Failed to generate: {failed[ri]}"))
+                continue
+            segs = [outs[(ri, ci)] for ci in range(len(r.chunks))]
+            r.future.set_result(TTSResponse(audio=np.concatenate(segs, axis=0), sample_rate=int(self.model.sample_rate), segments=len(segs),
+                                            phonemes=[ps for _, ps in r.chunks], batches=rode[ri]))
+        self.stats["requests"] += len(reqs)
+        self.stats["chunks"] += len(pool)
+        self.stats["rounds"] += 1
+
+    def _worker(self):
+        while True:
+            reqs = self._collect()
+            if reqs is None:
+                return
+            self.run_round(reqs)

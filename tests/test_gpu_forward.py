@@ -747,3 +747,56 @@ def test_pipeline_batch_scheduler_matches_chunk_by_chunk(tmp_path):
     for a, b in zip(seq, bat):
         np.testing.assert_array_equal(a.pred_dur.cpu().numpy(), b.pred_dur.cpu().numpy())
         assert a.audio.shape == b.audio.shape and torch.isfinite(b.audio).all()
+
+
+def test_tts_service_concurrent_requests_equal_sequential_ones(tmp_path):
+    """TTSService (the /tts handler's semantics, server.py:107-318, with request batching): N requests submitted concurrently ride shared padded
+    batches and each gets exactly the audio it gets when served alone (zero source noise: bit-identical), segments concatenated in text order."""
+    import threading
+
+    from mlx_audio_amd import _lib
+    from mlx_audio_amd.kokoro import Model, ModelConfig
+    from mlx_audio_amd.service import TTSError, TTSService
+
+    cfg = P.tiny_config()
+    cfg["vocab"] = P.load_vocab()
+    model = Model(ModelConfig.from_dict(dict(cfg, model_type="kokoro")), weights=P.synth_checkpoint(cfg, 0))
+    rows = np.load(os.path.join(GOLDEN, "af_heart_rows.npz"))["rows"]
+    voices = []
+    for v in range(2):
+        np.save(tmp_path / f"voice{v}.npy", np.stack([rows[(i + 7 * v) % rows.shape[0]] for i in range(510)])[:, None, :])
+        voices.append(str(tmp_path / f"voice{v}.npy"))
+    letters = [c for c in "abdefhijklmnopstuvwz" if c in cfg["vocab"]]
+    rng = np.random.default_rng(5)
+    texts = ["\n".join("".join(rng.choice(letters, n)) for n in ns) for ns in ((40, 6), (38,), (90, 7, 41), (5,), (88, 12), (33, 35, 36))]
+    speeds = ["1.0", "0.8", "1.25", "1.0", "2.0", "0.5"]
+    kw = dict(g2p=lambda t: (t, None), noise_mode=_lib.NOISE_ZERO, repo_id="local")
+    # sequential: one request per round
+    seq = []
+    with TTSService(model, max_batch=4, max_wait_ms=0.0, **kw) as svc:
+        for i, t in enumerate(texts):
+            seq.append(svc.tts(t, voice=voices[i % 2], speed=speeds[i], language="e"))
+    # concurrent: all requests inside one batching window
+    svc = TTSService(model, max_batch=4, max_wait_ms=500.0, **kw)
+    futs = [None] * len(texts)
+
+    def post(i):
+        futs[i] = svc.submit(texts[i], voice=voices[i % 2], speed=speeds[i], language="e")
+
+    th = [threading.Thread(target=post, args=(i,)) for i in range(len(texts))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    bad = svc.submit("text", speed="3.0")
+    con = [f.result(timeout=120) for f in futs]
+    svc.close()
+    assert isinstance(bad.exception(), TTSError) and bad.exception().status == 400
+    assert svc.stats["rounds"] == 1 and svc.stats["requests"] == len(texts) and svc.stats["chunks"] == 12
+    assert svc.stats["batches"] < 12  # chunks of different requests shared batches
+    shared = [set(c.batches) for c in con]
+    assert any(shared[i] & shared[j] for i in range(len(con)) for j in range(i))
+    for a, b, t in zip(seq, con, texts):
+        assert a.segments == b.segments == len(t.split("\n")) and a.phonemes == b.phonemes == t.split("\n")
+        assert a.audio.dtype == np.float32 and a.audio.ndim == 1 and a.audio.shape[0] % 600 == 0
+        np.testing.assert_array_equal(a.audio, b.audio)

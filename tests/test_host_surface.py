@@ -253,3 +253,31 @@ def test_dequantize_checkpoint_honours_per_layer_group_size_and_bits():
     assert out["y.weight"].shape == (16, 64) and np.abs(out["y.weight"] - b).max() < (b.max() - b.min()) / 15
     assert np.abs(out["x.weight"] - a).max() < (a.max() - a.min()) / 255
     assert out["z.weight"] is c
+
+
+def test_tts_service_request_semantics_and_pool_planner():
+    """The `/tts` handler's parameter rules (server.py:126-163, 193-220) and the cross-request batch planner, no GPU."""
+    from mlx_audio_amd.service import TTSError, TTSService, parse_request, plan_pool
+
+    assert parse_request("hi", None, "1.0", "a") == ("hi", "af_heart", 1.0, "a")
+    assert parse_request("hi", "bf_emma", "0.5", "british_english")[2:] == (0.5, "b")
+    assert parse_request("hi", "em_alex", "2", "klingon")[3] == "e"     # unknown language: first letter of the voice
+    assert parse_request("hi", "  ", "1", "klingon")[1:] == ("af_heart", 1.0, "a")  # blank voice = no voice
+    for bad, status, msg in ((("", None, "1.0", "a"), 400, "Text is empty"), (("   ", None, "1.0", "a"), 400, "Text is empty"),
+                             (("x", None, "fast", "a"), 400, "Invalid speed value"), (("x", None, "0.49", "a"), 400, "Speed must be between 0.5 and 2.0"),
+                             (("x", None, "2.5", "a"), 400, "Speed must be between 0.5 and 2.0")):
+        with pytest.raises(TTSError) as ei:
+            parse_request(*bad)
+        assert ei.value.status == status and ei.value.message == msg
+    # pooled planner: every chunk exactly once, batches bounded, padding waste bounded
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(3, 510, 200).tolist()
+    batches = plan_pool(lengths, 32)
+    assert sorted(i for b in batches for i in b) == list(range(200))
+    for b in batches:
+        assert 1 <= len(b) <= 32 and min(lengths[i] for i in b) >= 0.75 * max(lengths[i] for i in b)
+    # a request that fails validation never reaches the queue: its future already holds the error
+    svc = TTSService(model=None, start=False)
+    f = svc.submit("", speed="1.0")
+    assert f.done() and isinstance(f.exception(), TTSError) and f.exception().status == 400
+    assert svc._q.empty()
