@@ -163,6 +163,13 @@ int kk_op_source_stft(void* stream, int B, const float* f0, int L2_rows, const i
                       int dtype);
 /* exp/sin + MLXSTFT.inverse + istft  --  istftnet.py:804-806,497-523; mlx_audio/utils.py:104-158 */
 int kk_op_istft_head(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, float* wav, int dtype, int fast);
+/* The fused vocoder head of the bf16 mode: LeakyReLU(in_slope) -> conv_post (128 -> 22 channels, k = 7, pad 3) -> exp / sin -> inverse STFT ->
+ * overlap-add, one kernel (istftnet.py:798-806,497-523; mlx_audio/utils.py:104-158).  x: bf16 [B][Tf_rows][ldx], 128 channels.
+ * w_frag: conv_post in the kernel's fragment order, made by kk_op_pack_head_w from bf16 W[tap 7][cout 22][cin 128] (both DEVICE pointers,
+ * w_frag holds 7 * 8 * 64 * 8 bf16).  cp_out (nullable): the conv_post tensor, bf16 [B][Tf_rows][cp_ld >= 22]. */
+int kk_op_pack_head_w(void* stream, const void* w_bf16, void* w_frag);
+int kk_op_conv_post_istft(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, const void* w_frag,
+                          const float* bias, float in_slope, float* wav, void* cp_out, int cp_ld);
 
 /* MX-fp8 linear  --  the quantised nn.Linear of the reference's 8-bit checkpoints (mx.quantized_matmul, tts/utils.py:255-260).
  * kk_mxfp8_pack_weight (HOST to HOST): fp32 [N][K] -> e4m3 fragments + E8M0 scale bytes in MFMA fragment order, buffer sizes from

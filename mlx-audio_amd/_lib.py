@@ -71,6 +71,8 @@ SIGNATURES = {
     "kk_op_attention": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
     "kk_op_source_stft": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _vp, _i, _i]),
     "kk_op_istft_head": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "kk_op_pack_head_w": (_i, [_vp, _vp, _vp]),
+    "kk_op_conv_post_istft": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i]),
     "kk_debug_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kk_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_override": (_i, [_vp, C.c_char_p, _vp]),

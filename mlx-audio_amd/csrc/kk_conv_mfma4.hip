@@ -52,7 +52,7 @@ struct Geo {
   static constexpr int XROWS = BM + MAX_HALO;
   static constexpr int XS_BYTES = XROWS * XLD * 2;
   static constexpr int MAIN_BYTES = XS_BYTES + PS_BYTES;
-  static constexpr int RPP = BM == 128 ? 128 : BM / 2;  // rows per epilogue pass (one wave row group for the tall tiles)
+  static constexpr int RPP = BM / 2;  // rows per epilogue pass: one wave row group (64 or 96 rows)
   static constexpr int EPI_BYTES = RPP * CLD * 4;
   static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static constexpr int XREG = (XROWS * 8 + 255) / 256;  // 16-byte chunks of the slab per thread
@@ -70,8 +70,10 @@ union U32x8 {
 };
 
 // NRM: 0 = raw input, 1 = AdaIN + Snake while staging, 2 = AdaIN + LeakyReLU(nrm_slope; 1 = identity) while staging
+// WM = 96: 192-row tile, 2 workgroups per CU (230-256 VGPRs).  WM = 64: 128-row tile, 3 workgroups per CU (<= 168 VGPRs, 32 KB LDS): more
+// W traffic per MFMA, but a third workgroup to cover the serial prologue / slab staging / epilogue phases of the other two.
 template <typename TO, int WM, int NRM>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_mfma4_kernel(KKMfmaArgs a) {
+__global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_waves_per_eu((WM == 96 ? 2 : 3), (WM == 96 ? 2 : 3)))) void conv_mfma4_kernel(KKMfmaArgs a) {
   constexpr int BM = 2 * WM, MI = WM / 32;
   using G = Geo<BM>;
   constexpr int XREG = G::XREG;
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (tile_live) {
       if (pass > 0) __syncthreads();  // previous pass's readers are done with Cs
       // rows [RPP*pass, RPP*pass + RPP) of the block tile: tall tiles -> wave row `pass`; 128-row tile -> both wave rows
-      if (WM == 64 || wr == pass) {
+      if (wr == pass) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             const int col = wc * 64 + ni * 32 + (lane & 31);
-            const int rbase = (WM == 64 ? wr * 64 : 0) + mi * 32 + 4 * (lane >> 5);
+            const int rbase = mi * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];
           }
@@ -613,6 +615,11 @@ int kk_launch_conv_mfma4(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t 
   KKMfmaArgs g = a;
   if (nrm == 2 && a.nrm_act != KK_ACT_LRELU) g.nrm_slope = 1.0f;  // plain AdaIN: identity activation
   if (out_dtype != KK_BF16) return kk_fail("conv_mfma4: bf16 output only");
+  if (kk_mfma_tile_rows(a.Q) == 128) {
+    if (nrm == 1) return launch_one<bf16_t, 64, 1>(g, B, st);
+    if (nrm == 2) return launch_one<bf16_t, 64, 2>(g, B, st);
+    return launch_one<bf16_t, 64, 0>(g, B, st);
+  }
   if (nrm == 1) return launch_one<bf16_t, 96, 1>(g, B, st);
   if (nrm == 2) return launch_one<bf16_t, 96, 2>(g, B, st);
   return launch_one<bf16_t, 96, 0>(g, B, st);

@@ -219,6 +219,29 @@ int kk_launch_stft20(const float* har_source, int Nmax, const int* lenN, void* h
 // iSTFT head (istftnet.py:804-806,497-523; utils.py:104-158): x[b][t][22] -> wav[b][5*(frames-1)]
 int kk_launch_istft_head(const void* x, long long xbs, int ldx, const int* len_frames, int Tfmax, float* wav, long long wbs, int B,
                          int dtype, int fast, hipStream_t st);
+// fused vocoder head (kk_head.hip, bf16 mode): LeakyReLU -> conv_post (128 -> 22, k 7) -> exp / sin -> inverse STFT -> overlap-add
+struct KKHeadArgs {
+  const bf16_t* x;   // [B][Tfmax][ldx] stage-1 output of the generator (128 channels)
+  long long xbs;
+  int ldx;
+  const bf16_t* wf;  // conv_post weights in the head kernel's fragment order (kk_head_pack_index), output channels 22..31 zero
+  const float* bias; // [>= 22]
+  float in_slope;    // LeakyReLU on the input (istftnet.py:798: 0.01)
+  const int* len_frames;  // valid frames per utterance (null: Tfmax)
+  int Tfmax;
+  float* wav;        // [B][wbs] fp32, 5 * (Tfmax - 1) samples written per utterance
+  long long wbs;
+  bf16_t* cp_out;    // optional (debug): the conv_post tensor [B][Tfmax][cp_ld] as the stand-alone conv would have stored it
+  long long cp_bs;
+  int cp_ld;
+  float hann_per[20];  // periodic Hann (utils.py:121), for the partial window sums at utterance edges
+  int dbg;             // timing experiments only (KK_HEAD_DBG): bit 0 one k-step, bit 1 no frame arithmetic, bit 2 cache-resident input
+};
+bool kk_head_eligible(int Cin, int Cout, int Kw, int n_fft, int hop);
+long long kk_head_pack_index(int tap, int cout, int cin);
+size_t kk_head_pack_elems();
+int kk_launch_conv_post_istft(const KKHeadArgs& a, int B, hipStream_t st);
+int kk_launch_pack_head_w(const bf16_t* w, bf16_t* wf, hipStream_t st);  // device-side re-layout [7][22][128] -> fragment order (tests)
 // dtype-converting strided copy (debug hooks)
 int kk_launch_set_u64(unsigned long long* dst, unsigned long long v, hipStream_t st);  // one 8-byte device store (graph-replay seed)
 int kk_launch_convert(const void* src, int sdt, long long sbs, int lds, void* dst, int ddt, long long dbs, int ldd, int C, int rows, int B,

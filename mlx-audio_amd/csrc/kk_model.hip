@@ -168,6 +168,10 @@ struct kk_model {
   bool capturing = false;
   bool no_v4 = false;
   bool no_fp8 = false;  // tests: quantised model, but the Q1 layer set runs on the bf16 kernel with the same (dequantised) weights
+  bool no_head_fusion = false;  // tests / A-B: stand-alone conv_post + iSTFT head kernels instead of the fused head (kk_head.hip)
+  bool keep_debug = false;      // tests: also materialise the tensors fused kernels skip (conv_post)
+  size_t head_wf_off = 0;       // conv_post in the fused head's fragment order (bf16), 0 = not eligible
+  const bf16_t* head_wf = nullptr;
   int q_group = 0;      // kk_set_quantization: group size of the MLX affine quantisation the checkpoint went through (0 = none)
   hipStream_t cap_stream = nullptr;
   struct ProfRec { int cls; double flops; double bytes; };
@@ -710,6 +714,17 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
           build_resblock1(P, SD, g + "resblocks." + std::to_string(i * nk + j), cout, c.resblock_kernel_sizes[j], c.resblock_dilations[j]));
   }
   m->conv_post = P.convw(g + "conv_post", c.gen_istft_n_fft + 2, 7, C0 >> c.n_upsamples, true);
+  if (P.ok() && m->adt == KK_BF16 && m->conv_post.mfma &&
+      kk_head_eligible(m->conv_post.Cin, m->conv_post.Cout, m->conv_post.Kw, c.gen_istft_n_fft, c.gen_istft_hop_size)) {
+    // the fused head (kk_head.hip) reads conv_post in its own fragment order: the same bf16 values as the MFMA pack
+    const ConvW& cp = m->conv_post;
+    m->head_wf_off = P.alloc((kk_head_pack_elems() + 1) / 2);  // zero-filled: output columns 22..31 are padding
+    const uint16_t* src = (const uint16_t*)&m->pack[cp.wb_off];
+    uint16_t* dst = (uint16_t*)&m->pack[m->head_wf_off];
+    for (int t = 0; t < cp.Kw; ++t)
+      for (int o = 0; o < cp.Cout; ++o)
+        for (int i = 0; i < cp.Cin; ++i) dst[kk_head_pack_index(t, o, i)] = src[((size_t)t * cp.CoutP + o) * cp.CinP + i];
+  }
   if (P.ok()) {
     SP.build(P, m->sp_wT, m->sp_b, m->Np);
     SD.build(P, m->sd_wT, m->sd_b, m->Nd);
@@ -727,6 +742,7 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   ConvW* convs[] = {&m->map_in, &m->qkv, &m->att_dense, &m->ffn, &m->ffn_out, &m->bert_encoder, &m->f0_proj, &m->n_proj,
                     &m->f0_conv, &m->n_conv, &m->asr_res, &m->conv_post};
   for (ConvW* cw : convs) resolve(m, *cw);
+  m->head_wf = m->head_wf_off ? (const bf16_t*)(m->dev + m->head_wf_off) : nullptr;
   for (auto& l : m->dur_lstms) resolve(m, l);
   resolve(m, m->pred_lstm); resolve(m, m->shared_lstm); resolve(m, m->text_lstm);
   for (int i = 0; i < 3; ++i) { resolve(m, m->f0blk[i]); resolve(m, m->nblk[i]); }
@@ -889,7 +905,7 @@ struct Ctx {
         g.stat_ntiles = last_ntiles;
       }
       // variant 4 (W fragments straight into registers): bf16 outputs at the default 192-row tile
-      const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4 && kk_mfma_tile_rows(Q) == 192;
+      const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4;
       g.wf = v4 ? w.wf : nullptr;
       prof_start();
       const int rc = v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
@@ -1460,6 +1476,25 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   }
   // ---- conv_post + iSTFT head (istftnet.py:798-806)
   Buf cp = c.act(Tf, 24);
+  if (m->head_wf && !m->no_head_fusion && !m->force_generic && cur.dtype == KK_BF16 && cur.ld % 8 == 0 && cur.ld >= m->conv_post.Cin &&
+      !((uintptr_t)cur.p & 15) && m->dbg_over.find("conv_post") == m->dbg_over.end()) {
+    // one kernel: the 22-channel tensor never exists in HBM (kk_head.hip); `keep_debug` also writes it for kk_debug_fetch
+    if (!c.dry) {
+      KKHeadArgs h;
+      memset(&h, 0, sizeof h);
+      h.x = (const bf16_t*)cur.p; h.xbs = cur.bs; h.ldx = cur.ld; h.wf = m->head_wf; h.bias = m->conv_post.b; h.in_slope = 0.01f;
+      h.len_frames = lens4 + 2 * B; h.Tfmax = Tf; h.wav = wav_out; h.wbs = (long long)Nw;
+      if (m->keep_debug) { h.cp_out = (bf16_t*)cp.p; h.cp_bs = cp.bs; h.cp_ld = cp.ld; }
+      for (int n = 0; n < 20; ++n) h.hann_per[n] = (float)(0.5 * (1.0 - cos(2.0 * 3.14159265358979323846 * n / 20.0)));
+      if (m->keep_debug && hipMemsetAsync(cp.p, 0, (size_t)B * cp.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
+      c.prof_start();
+      KK_TRY(kk_launch_conv_post_istft(h, B, c.st));
+      // algorithmic bytes of the fused head: 128 bf16 channels in + 5 fp32 samples out per frame column
+      c.prof_stop(5, B * (double)Tf * (2.0 * 22 * 128 * 7 + 800.0), (double)B * Tf * (128.0 * 2.0 + 20.0));
+    }
+    KK_TRY(c.dbg("conv_post", cp, 22));
+    return 0;
+  }
   ConvOpt op;
   op.pad = 3;
   op.in_slope = 0.01f;
@@ -1553,7 +1588,8 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
       (unsigned long long)(uintptr_t)ref_s, (unsigned long long)(uintptr_t)speed, (unsigned long long)(uintptr_t)forced_dur,
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
-      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4};
+      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4,
+      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug};
   kk_model::GraphEntry* ge = nullptr;
   for (auto& g : m->graphs)
     if (g.key == key) ge = &g;
@@ -1752,6 +1788,23 @@ extern "C" int kk_op_istft_head(void* stream, int B, const void* x, int ldx, int
                               (hipStream_t)stream);
 }
 
+extern "C" int kk_op_pack_head_w(void* stream, const void* w_bf16, void* w_frag) {
+  if (!w_bf16 || !w_frag) return kk_fail("kk_op_pack_head_w: null argument");
+  return kk_launch_pack_head_w((const bf16_t*)w_bf16, (bf16_t*)w_frag, (hipStream_t)stream);
+}
+extern "C" int kk_op_conv_post_istft(void* stream, int B, const void* x, int ldx, int Tf_rows, const int32_t* len_frames, const void* w_frag,
+                                     const float* bias, float in_slope, float* wav, void* cp_out, int cp_ld) {
+  if (!x || !w_frag || !bias || !wav) return kk_fail("kk_op_conv_post_istft: null argument");
+  KKHeadArgs h;
+  memset(&h, 0, sizeof h);
+  h.x = (const bf16_t*)x; h.xbs = (long long)Tf_rows * ldx; h.ldx = ldx; h.wf = (const bf16_t*)w_frag; h.bias = bias; h.in_slope = in_slope;
+  h.len_frames = len_frames; h.Tfmax = Tf_rows; h.wav = wav; h.wbs = (long long)5 * (Tf_rows - 1);
+  h.cp_out = (bf16_t*)cp_out; h.cp_bs = (long long)Tf_rows * cp_ld; h.cp_ld = cp_ld;
+  for (int n = 0; n < 20; ++n) h.hann_per[n] = (float)(0.5 * (1.0 - cos(2.0 * 3.14159265358979323846 * n / 20.0)));
+  if (const char* e = getenv("KK_HEAD_DBG")) h.dbg = atoi(e);  // timing experiments (tools/bench_head.py)
+  return kk_launch_conv_post_istft(h, B, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // debug hooks
 // ------------------------------------------------------------------------------------------------
@@ -1781,6 +1834,8 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
   m->no_v4 = (on & 4) != 0;          // bit 2: the LDS-staged MFMA kernel (variant 2) instead of variant 4
   m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
+  m->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
+  m->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
 }
 
 // load_model's quantization branch (mlx_audio/tts/utils.py:241-260): the checkpoint's Linear / Embedding weights went through MLX's

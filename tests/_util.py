@@ -30,6 +30,7 @@ def err_stats(got, ref):
         "rel_max": float(d.max() / scale) if d.size else 0.0,
         "rms_rel": float(np.sqrt((d**2).mean()) / max(1e-12, np.sqrt((ref**2).mean()))) if d.size else 0.0,
         "p9999_abs": float(np.quantile(d, 0.9999)) if d.size else 0.0,
+        "p99_abs": float(np.quantile(d, 0.99)) if d.size else 0.0,
     }
 
 

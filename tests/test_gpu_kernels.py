@@ -435,6 +435,54 @@ def test_istft_head_fast_path(lib, dtype):
     report(f"istft_head_fast/{dtype}", worst_rel_max=worst)
 
 
+def test_fused_conv_post_istft_head(lib):
+    """kk_head.hip: LeakyReLU(0.01) -> conv_post (128 -> 22, k 7, pad 3) -> exp / sin -> inverse STFT -> overlap-add in ONE kernel, against
+    torch's conv1d on the same bf16 operands (fp32 accumulation) followed by the oracle's iSTFT head (istftnet.py:798-806,497-523;
+    utils.py:104-158).  Utterance lengths put edges at every interesting position of the 253-hop-block tiles and the 64-lane waves; the
+    bounds are those of test_istft_head_fast_path (the iSTFT arithmetic is shared, kk_istft_math.h)."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(18)
+    lens = [1013, 1, 2, 3, 4, 5, 61, 64, 65, 250, 251, 252, 253, 254, 255, 256, 257, 259, 505, 506, 507, 508, 759, 1012]
+    B, Tf, C = len(lens), 1013, 128
+    x = torch.tensor(rng.standard_normal((B, Tf, C)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.tensor((rng.standard_normal((7, 22, C)) * (0.6 / (7 * C) ** 0.5)).astype(np.float32)).to(torch.bfloat16)  # [tap][cout][cin]
+    bias = (rng.standard_normal(22) * 0.3).astype(np.float32)
+    xd, wd, bd = x.cuda(), w.cuda(), dev(bias)
+    for b, n in enumerate(lens):
+        xd[b, n:] = 0  # rows past an utterance hold zeros in the model (every producer writes them)
+    wf = torch.empty(7 * 8 * 64 * 8, dtype=torch.bfloat16, device="cuda")
+    assert lib.kk_op_pack_head_w(stream(), P(wd), P(wf)) == 0, lib.kk_last_error()
+    wav = torch.full((B, 5 * (Tf - 1)), 4.0, device="cuda")
+    cp = torch.full((B, Tf, 24), 9.0, dtype=torch.bfloat16, device="cuda")
+    lend = dev(np.asarray(lens, np.int32), torch.int32)
+    rc = lib.kk_op_conv_post_istft(stream(), B, P(xd), C, Tf, P(lend), P(wf), P(bd), 0.01, P(wav), P(cp), 24)
+    assert rc == 0, lib.kk_last_error()
+    torch.cuda.synchronize()
+    got, cpg = wav.cpu().numpy(), cp.float().cpu().numpy()
+    orc = _oracle_stub()
+    worst, worst_cp = 0.0, 0.0
+    for b, n in enumerate(lens):
+        xi = F.leaky_relu(x[b : b + 1, :n].float(), 0.01).to(torch.bfloat16).float()  # the kernel rounds the activated input to bf16
+        y = F.conv1d(xi.transpose(1, 2), w.float().permute(1, 2, 0).contiguous(), torch.tensor(bias), padding=3).numpy()  # [1, 22, n]
+        e = err_stats(cpg[b, :n, :22], y[0].T)
+        worst_cp = max(worst_cp, e["rel_max"])
+        assert e["rel_max"] < 8e-3, (n, e)  # conv_post as stored for the debug hook: one bf16 rounding
+        assert np.all(cpg[b, n:, :22] == 9.0)  # (rows past the utterance are not written by the kernel; the model zero-fills the buffer)
+        if n > 1:
+            ref = orc.istft_head(y.astype(np.float32))[0, 0]
+            e = err_stats(got[b, : 5 * (n - 1)], ref)
+            worst = max(worst, e["rel_max"])
+            assert e["rel_max"] < 1e-4, (n, e)
+        assert np.all(got[b, 5 * (n - 1) :] == 0), n
+    report("fused_head", worst_rel_max_wav=worst, worst_rel_max_conv_post=worst_cp)
+    # no debug tensor: same waveform bits
+    wav2 = torch.full((B, 5 * (Tf - 1)), 4.0, device="cuda")
+    assert lib.kk_op_conv_post_istft(stream(), B, P(xd), C, Tf, P(lend), P(wf), P(bd), 0.01, P(wav2), None, 0) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(wav, wav2)
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 MFMA convolution kernel
 # ------------------------------------------------------------------------------------------------
