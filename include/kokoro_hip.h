@@ -255,7 +255,8 @@ int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);
 
 /* =====================================================================================================================
  * CSM-1B frame generator (rows C1-C3): SesameModel.generate_frame, mlx_audio/tts/models/sesame/sesame.py:349-395, with the
- * Llama stacks of mlx_lm (LlamaModel + the reference's Attention / Llama3ScaledRoPE, attention.py).  fp32 in round 1.
+ * Llama stacks of mlx_lm (LlamaModel + the reference's Attention / Llama3ScaledRoPE, attention.py).  fp32 arithmetic; in bf16 weight
+ * mode the single-token steps run as five launches per layer on the fused GEMV (no split-K partials, norm / SwiGLU / residual fused).
  * ===================================================================================================================== */
 typedef struct kk_csm kk_csm;
 typedef struct kk_llama_args { /* sesame.py:225-273 */
@@ -281,6 +282,10 @@ int kk_csm_finalize(kk_csm* m, void* stream);
 int kk_csm_setup_caches(kk_csm* m, int max_batch); /* SesameModel.setup_caches (sesame.py:320-333): library-owned KV caches */
 int kk_csm_reset_caches(kk_csm* m);                /* sesame.py:338-345: positions restart at 0 */
 int kk_csm_position(const kk_csm* m);              /* tokens in the backbone cache */
+/* Ragged prompts in one batch (the reference's generate is batch 1, sesame.py:689-817): the prompts are LEFT-padded to the longest one
+ * (padding frames: all-zero mask) and pad[b] (HOST array, B entries) says how many padding frames item b has.  Item b's token in cache
+ * slot p then sits at position p - pad[b] and attends to slots >= pad[b] only: bit-identical to running the item alone.  Empty cache only. */
+int kk_csm_set_padding(kk_csm* m, int B, const int32_t* pad_host);
 size_t kk_csm_workspace_bytes(kk_csm* m, int B, int S);
 /* One audio frame.  tokens [B][S][n_cb+1] int32 and tokens_mask (same shape, float 0/1) on the device; the S new positions continue
  * the backbone cache (a block of S > 1 must start an empty cache, as index_causal_mask implies, sesame.py:41-48).  Sampling:

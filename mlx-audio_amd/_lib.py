@@ -87,6 +87,7 @@ SIGNATURES = {
     "kk_csm_setup_caches": (_i, [_vp, _i]),
     "kk_csm_reset_caches": (_i, [_vp]),
     "kk_csm_position": (_i, [_vp]),
+    "kk_csm_set_padding": (_i, [_vp, _i, _vp]),
     "kk_csm_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_csm_generate_frame": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "kk_csm_set_graph_mode": (_i, [_vp, _i]),

@@ -44,6 +44,7 @@ class SesameModel:
         self._final = False
         self._ws = None
         self._enabled = False
+        self.max_batch = 0
         self._graph = False
         self._gbuf = {}
         if weights is not None:
@@ -76,6 +77,13 @@ class SesameModel:
             check(self.lib.kk_csm_setup_caches(self._h, int(max_batch_size)), "kk_csm_setup_caches")
         self._gbuf = {}  # the library dropped its captured graphs with the old caches; their staging buffers go with them
         self._enabled = True
+        self.max_batch = int(max_batch_size)
+
+    def set_padding(self, pads) -> None:
+        """kk_csm_set_padding: left padding (in frames) of every stream's prompt, for batches whose prompts differ in length.  Call on an
+        empty cache, before the prompt block; reset_caches clears it."""
+        arr = (C.c_int32 * len(pads))(*[int(p) for p in pads])
+        check(self.lib.kk_csm_set_padding(self._h, len(pads), arr), "kk_csm_set_padding")
 
     def caches_are_enabled(self) -> bool:
         return self._enabled

@@ -25,9 +25,11 @@ struct Lin {  // generic-kernel pack [1][Cin][ldw]
   size_t off = 0;
   int Cin = 0, Cout = 0, ldw = 0;
   const float* w = nullptr;
-  // bf16 weight mode (kk_csm_set_weight_dtype): the same matrix as bf16 [Cin][ldw] for the single-token skinny GEMM
+  // bf16 weight mode (kk_csm_set_weight_dtype): the same matrix as bf16 in COLUMN-BLOCK order for the fused GEMV of the single-token
+  // steps: [Cout / CB][Cin][CB] with CB = 8 * oct columns per workgroup, so a workgroup streams one contiguous region
   size_t boff = 0;
   const uint16_t* wb = nullptr;
+  int oct = 0;  // 0 = no block pack (K not a multiple of 64)
 };
 struct Vec {
   size_t off = 0;
@@ -46,6 +48,7 @@ struct Stack {
   float* vc = nullptr;
   int max_pos = 0, offset = 0;
   int* pos_dev = nullptr;  // backbone only: device copy of `offset` (null: positions are launch constants)
+  int* pad_dev = nullptr;  // backbone only: [max_batch] left padding of each item's prompt (kk_csm_set_padding), zeros by default
 };
 
 }  // namespace
@@ -127,13 +130,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const floa
 }
 
 // RoPE on q (in place) and k, then k / v of the new rows go into the cache at [offset + s]
+// `pad` (nullable, [B]): ragged prompts are LEFT-padded to a common length; item b's first pad[b] cache slots hold nothing, its token in
+// slot p sits at position p - pad[b] (RoPE) and attends to slots >= pad[b] only.  Padding rows are rotated with position 0 (never read).
 __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int H, int KV, int hd, const float* rope, const int* pos_dev, int offset,
-                                                          float* kc, float* vc, int max_pos) {
+                                                          float* kc, float* vc, int max_pos, const int* pad) {
   const int s = blockIdx.x, b = blockIdx.y;
   if (pos_dev) offset += *pos_dev;  // the backbone's position lives in device memory so that a captured frame step can be replayed
   const int W = (H + 2 * KV) * hd, half = hd / 2;
   float* row = qkv + ((long long)b * S + s) * W;
-  const float* cs = rope + (long long)(offset + s) * half * 2;
+  const int pd = pad ? pad[b] : 0;
+  const int rpos = offset + s - pd > 0 ? offset + s - pd : 0;
+  const float* cs = rope + (long long)rpos * half * 2;
   float* kdst = kc + ((long long)b * max_pos + offset + s) * KV * hd;
   float* vdst = vc + ((long long)b * max_pos + offset + s) * KV * hd;
   for (int e = threadIdx.x; e < (H + KV) * half; e += 256) {
@@ -165,13 +172,19 @@ __global__ __launch_bounds__(256) void rope_append_kernel(float* qkv, int S, int
 // query head of each kv group writes it to the cache for the steps to come (the other heads of the group never read that row here).
 template <bool FUSE>
 __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S, int H, int KV, int hd, const int* pos_dev, int offset, float* kc,
-                                                         float* vc, int max_pos, float scale, float* out, int causal, int ctx, const float* rope) {
+                                                         float* vc, int max_pos, float scale, float* out, int causal, int ctx, const float* rope,
+                                                         const int* pad) {
   extern __shared__ __attribute__((aligned(16))) float sc[];  // [max_pos] scores, [hd] q, [G][hd] partial outputs, [hd] new k, [hd] new v
   __shared__ float red[2];
   if (pos_dev) offset += *pos_dev;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  const int klo = ctx >= 0 && offset > ctx ? offset - ctx : 0;
+  const int pd = pad ? pad[b] : 0;  // left padding of a ragged prompt: the keys start at slot pd, key j of the walk is slot klo + j as before
+  const int klo = ctx >= 0 && offset > ctx ? offset - ctx : pd;
   const int W = (H + 2 * KV) * hd, kvh = h / (H / KV), nk = (causal ? offset + s + 1 : offset + S) - klo;
+  if (nk <= 0) {  // a padding row: no key, the output is defined as zero (nothing reads it)
+    for (int e = tid; e < hd; e += 128) out[((long long)b * S + s) * H * hd + h * hd + e] = 0.f;
+    return;
+  }
   const int mp4 = (max_pos + 3) & ~3;
   float* qs = sc + mp4;        // [hd]
   float* po = qs + hd;         // [G][hd]
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   const float* vb = vc + ((long long)b * max_pos + klo) * KV * hd + kvh * hd;
   const int jn = FUSE ? nk - 1 : -1;  // the key that is not in the cache yet
   if (FUSE) {
-    const float* cs = rope + (long long)(offset + s) * (hd / 2) * 2;
+    const float* cs = rope + (long long)(offset + s - pd) * (hd / 2) * 2;
     const float* kq = qkv + ((long long)b * S + s) * W + (H + kvh) * hd;
     const float* vq = qkv + ((long long)b * S + s) * W + (H + KV + kvh) * hd;
     for (int i = tid; i < hd / 2; i += 128) {
@@ -569,6 +582,269 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, i
   out[e] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Fused GEMV of the single-token steps (bf16 weight mode): out[m][n] = sum_k f(x)[m][k] W[k][n] for M <= 16 rows, with NO split-K through
+// HBM and no separate reduce / norm / activation launches -- a Llama layer is five launches (qkv, attention, o, gate|up, down).
+//   * a workgroup owns CB = 8 * OCT output columns for ALL of K; the weights are packed [N / CB][K][CB] (bf16), so it streams one contiguous
+//     region: lane = (k-sub, column octet) takes 16 bytes = 8 columns of one k row, a wave instruction covers 64 / OCT consecutive k rows
+//     (1 KiB contiguous), U of them in flight per thread; OCT = 1 for the narrow matrices (>= 128 workgroups even for N = 1024), 8 for gate|up;
+//   * the input rows live in LDS as xs[row quad][k][4] fp32, staged per 1024-row K chunk with the PROLOGUE applied on the way in:
+//       PRO 0 plain rows; PRO 1 RMSNorm(x) * w (every workgroup recomputes the row norms: M x K floats from L2, against its own 16-256 KB of
+//       weights); PRO 2 silu(gate) * up of a gate|up pair; PRO 3 rows gathered from the audio embedding table by code (the depth decoder's
+//       input `curr`, sesame.py:373-392), for two-row items the first row from x;
+//   * a weight meets all rows in packed fp32 FMAs (accumulators acc[8 columns][MT / 2 row pairs]); per lane the k order is fixed by the
+//     layout, so a row's bits do not depend on its batch neighbours or on MT;
+//   * the lanes' / waves' partial sums meet in LDS in a fixed order; EPI 1 adds the residual (h += ...) in place.
+constexpr int FG_U = 4;
+struct FGArgs {
+  const float* x; long long xrs;   // input row m at x + m * xrs (PRO 2: 2K floats, gate | up)
+  const float* nw; float eps;      // PRO 1
+  const int* codes; int cstride, cb, V, rows; const float* emb;  // PRO 3: row m is item m / rows; its LAST row is emb[(codes[item * cstride] + cb * V)], others come from x
+  const uint16_t* w;
+  int K, N, M;
+  const float* res; long long rrs;  // EPI 1
+  float* out; long long ors;
+  long long pss;                    // EPI 2: floats between the partial tiles of consecutive K slices
+};
+
+// h[m][n] += sum over the K slices of a split-K launch (slice order): the combine of the deep down projections
+__global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, int KS, long long pss, long long n, float* h) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  // all slices are requested at once (a plain loop is KS dependent L2 round trips); KS <= 16 (gemv_slices)
+  float v[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) v[ks] = part[(long long)(ks < KS ? ks : 0) * pss + e];
+  const float h0 = h[e];
+  float t = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) t += ks < KS ? v[ks] : 0.f;
+  h[e] = h0 + t;
+}
+
+template <int MT, int OCT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
+  constexpr int CB = 8 * OCT, KSUB = 64 / OCT, MP = MT / 2, NQ = MT / 4, OUT = CB * 8;
+  constexpr int KCH = 16384 / MT;           // k rows staged at a time: xs is 64 KB (2048 rows for 8 input rows, 1024 for 16)
+  constexpr int NH = PRO == 2 ? 2 : 1;      // the gated prologue holds two values per item: two half passes
+  constexpr int NPRE = 8;                   // weight loads requested before the prologue (all of them for K <= 2048 on 8-column blocks)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;                                   // [NQ][KCH][4]
+  float* red = sm;                                  // [4 waves][KSUB][OUT] (aliases xs after the main loop)
+  float* red2 = sm + 4 * KSUB * OUT;                // [4][OUT]
+  float* rs = red2 + 4 * OUT;                       // [16] row scales (PRO 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int oct = lane % OCT, ksub = lane / OCT;
+  const int nb = blockIdx.x;
+  const int K = a.K, M = a.M;
+  // split-K (gridDim.y > 1, the deep down projections): this workgroup owns k rows [k_lo, k_hi) and writes a partial tile
+  const int Kper = K / gridDim.y, k_lo = blockIdx.y * Kper, k_hi = k_lo + Kper;
+  const uint4* wblk = (const uint4*)(a.w + (long long)nb * K * CB) + oct;  // row k of the block at + k * OCT uint4
+  // ---- the first NPRE weight loads of this wave go out before anything else: they do not depend on the input rows
+  uint4 wpre[NPRE];
+  {
+    const int kn0 = min(KCH, k_hi - k_lo), nL0 = kn0 / KSUB;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int L = wave + 4 * i;
+      wpre[i] = wblk[(long long)(k_lo + (L < nL0 ? L : wave % nL0) * KSUB + ksub) * OCT];
+    }
+  }
+  // input row m of this launch as an element offset from its base (PRO 3: an item's last row comes from the audio embedding table,
+  // sesame.py:373-392, its other rows from x)
+  int rowoff[MT];
+  bool rowemb[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mm = m < M ? m : 0;
+    rowemb[m] = false;
+    if (PRO == 3) {
+      const int item = mm / a.rows, r = mm - item * a.rows;
+      rowemb[m] = r == a.rows - 1;
+      rowoff[m] = rowemb[m] ? (a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : (int)(item * a.xrs);
+    } else {
+      rowoff[m] = (int)(mm * a.xrs);
+    }
+  }
+  auto rowptr = [&](int m) __attribute__((always_inline)) -> const float* { return (PRO == 3 && rowemb[m] ? a.emb : a.x) + rowoff[m]; };
+  if (PRO == 1 && K > KCH) {  // rows longer than a chunk (16 input rows of the backbone): the row scales need their own pass
+    float ssr[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ssr[m] = 0.f;
+    const int n4 = K >> 2;
+    for (int c0 = tid; c0 < n4; c0 += 256 * 2) {
+      float4 v[2][MT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) v[i][m] = *((const float4*)rowptr(m) + (c0 + 256 * i < n4 ? c0 + 256 * i : c0));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float live = c0 + 256 * i < n4 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ssr[m] += live * (((v[i][m].x * v[i][m].x + v[i][m].y * v[i][m].y) + v[i][m].z * v[i][m].z) + v[i][m].w * v[i][m].w);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float t = ssr[m];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) red2[wave * 16 + m] = t;
+    }
+    __syncthreads();
+    if (tid < MT) rs[tid] = 1.0f / sqrtf((((red2[tid] + red2[16 + tid]) + red2[32 + tid]) + red2[48 + tid]) / (float)K + a.eps);
+  }
+  sk2f acc[8][MP];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int i = 0; i < MP; ++i) acc[c][i] = sk2f{0.f, 0.f};
+  for (int kc = k_lo; kc < k_hi; kc += KCH) {
+    const int kn = min(KCH, k_hi - kc);
+    const int total = NQ * kn;
+    __syncthreads();  // (the previous chunk's readers are done)
+    // ---- stage the chunk: thread t takes k = t, t + 256, ... and reads that column of EVERY input row (coalesced along k), one 16-byte LDS
+    // store per row quad.  All of a pass's loads are requested before anything is computed; with the norm prologue the row norms come out
+    // of the same registers (x is read once).
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      constexpr int NIK = KCH / 256 / NH;  // k values per thread and pass
+      float g[NIK][MT], u[PRO == 2 ? NIK : 1][MT];
+#pragma unroll
+      for (int i = 0; i < NIK; ++i) {
+        const int k = tid + 256 * (hh * NIK + i);
+        const int kk = kc + (k < kn ? k : tid % kn);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          g[i][m] = rowptr(m)[kk];
+          if (PRO == 2) u[i][m] = rowptr(m)[K + kk];
+        }
+      }
+      if (PRO == 1 && K <= KCH) {  // the whole row is in this chunk: sums of squares from the registers
+        float ssq[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NIK; ++i)
+          if (tid + 256 * i < kn)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ssq[m] = __builtin_fmaf(g[i][m], g[i][m], ssq[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          float t = ssq[m];
+          for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+          if (lane == 0) red2[wave * 16 + m] = t;
+        }
+        __syncthreads();
+        if (tid < MT) rs[tid] = 1.0f / sqrtf((((red2[tid] + red2[16 + tid]) + red2[32 + tid]) + red2[48 + tid]) / (float)K + a.eps);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int i = 0; i < NIK; ++i) {
+        const int k = tid + 256 * (hh * NIK + i);
+        if (k < kn) {
+          const float nwk = PRO == 1 ? a.nw[kc + k] : 1.0f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int m = 4 * q + j;
+              float t = g[i][m];
+              if (PRO == 2) t = t / (1.0f + expf(-t)) * u[i][m];
+              else if (PRO == 1) t = t * rs[m] * nwk;
+              v[j] = m < M ? t : 0.f;
+            }
+            *(float4*)(xs + ((long long)q * KCH + k) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int nL = kn / KSUB;  // wave loads in this chunk; wave w takes L = w, w + 4, ...
+    auto fma_row = [&](const uint4& wq, int kl, float live) __attribute__((always_inline)) {
+      sk2f xv[MP];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 t = *(const float4*)(xs + ((long long)q * KCH + kl) * 4);
+        xv[2 * q] = sk2f{t.x, t.y};
+        xv[2 * q + 1] = sk2f{t.z, t.w};
+      }
+      const unsigned wd[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) {
+        const float w0 = __uint_as_float(wd[c2] << 16) * live, w1 = __uint_as_float(wd[c2] & 0xffff0000u) * live;
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp) {
+          acc[2 * c2][mp] = __builtin_elementwise_fma(xv[mp], sk2f{w0, w0}, acc[2 * c2][mp]);
+          acc[2 * c2 + 1][mp] = __builtin_elementwise_fma(xv[mp], sk2f{w1, w1}, acc[2 * c2 + 1][mp]);
+        }
+      }
+    };
+    int Lstart = wave;
+    if (kc == k_lo) {  // the preloaded rows of the first chunk
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int L = wave + 4 * i;
+        fma_row(wpre[i], (L < nL ? L : wave % nL) * KSUB + ksub, L < nL ? 1.0f : 0.0f);
+      }
+      Lstart = wave + 4 * NPRE;
+    }
+    for (int L0 = Lstart; L0 < nL; L0 += 4 * FG_U) {
+      uint4 wv[FG_U];
+      int kl[FG_U];
+#pragma unroll
+      for (int i = 0; i < FG_U; ++i) {  // unconditional (clamped) loads: a load under a data-dependent branch is waited for on the spot
+        const int L = L0 + 4 * i;
+        kl[i] = (L < nL ? L : L0) * KSUB + ksub;
+        wv[i] = wblk[(long long)(kc + kl[i]) * OCT];
+      }
+#pragma unroll
+      for (int i = 0; i < FG_U; ++i) fma_row(wv[i], kl[i], L0 + 4 * i < nL ? 1.0f : 0.0f);
+    }
+  }
+  // ---- reduction over the lanes that share columns (k-sub) and the 4 waves, 8 rows per pass; output o = mloc * CB + column
+#pragma unroll
+  for (int mh = 0; mh < MT / 8; ++mh) {
+    __syncthreads();  // the chunk (or the previous pass) is no longer read
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* d = red + ((long long)(wave * KSUB + ksub)) * OUT + oct * 8 + c;
+        d[(2 * i) * CB] = acc[c][4 * mh + i].x;
+        d[(2 * i + 1) * CB] = acc[c][4 * mh + i].y;
+      }
+    __syncthreads();
+    for (int pr = tid; pr < 4 * OUT; pr += 256) {  // (wave q, output o): the q-th wave's KSUB lanes in k-sub order
+      const int q = pr / OUT, o = pr - q * OUT;
+      const float* sp = red + (long long)q * KSUB * OUT + o;
+      float t = 0.f;
+#pragma unroll 8
+      for (int ks = 0; ks < KSUB; ++ks) t += sp[(long long)ks * OUT];
+      red2[pr] = t;
+    }
+    __syncthreads();
+    for (int o = tid; o < OUT; o += 256) {
+      const int mloc = o / CB, col = o - mloc * CB;
+      const int m = 8 * mh + mloc, n = nb * CB + col;
+      if (m < M && n < a.N) {
+        float t = ((red2[o] + red2[OUT + o]) + red2[2 * OUT + o]) + red2[3 * OUT + o];  // wave order
+        if (EPI == 1) t += a.res[(long long)m * a.rrs + n];
+        if (EPI == 2) a.out[(long long)blockIdx.y * a.pss + (long long)m * a.ors + n] = t;  // K slice blockIdx.y of a split-K launch
+        else a.out[(long long)m * a.ors + n] = t;
+      }
+    }
+  }
+}
+
+template <int MT, int OCT>
+static size_t fg_lds_bytes() {
+  constexpr size_t xsb = (size_t)65536, redb = (size_t)4 * (64 / OCT) * (8 * OCT * 8) * 4;
+  return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64;
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 struct Packer {
   kk_csm* m;
@@ -628,18 +904,28 @@ struct Packer {
     }
     if (m->wdt == KK_BF16) {
       // bf16 weight mode: the matrix IS its bf16 rounding everywhere (the fp32 pack the multi-token prompt block reads holds the rounded
-      // values too, so a prompt block and single-token steps multiply by identical weights); lossless for a bf16 checkpoint
-      l.boff = m->packb.size();
-      m->packb.resize(l.boff + (size_t)I * l.ldw, 0);
+      // values too, so a prompt block and single-token steps multiply by identical weights); lossless for a bf16 checkpoint.  The bf16
+      // copy is laid out for the fused GEMV: [Cout / CB][Cin][CB], CB = 8 * oct columns per workgroup (fused_gemv_kernel).
       float* dst = &m->pack[l.off];
-      uint16_t* db = &m->packb[l.boff];
       for (size_t e = 0; e < (size_t)I * l.ldw; ++e) {
         uint32_t u;
         memcpy(&u, &dst[e], 4);
         if ((u & 0x7FFFFFFFu) <= 0x7F800000u) u += 0x7FFFu + ((u >> 16) & 1u);
-        db[e] = (uint16_t)(u >> 16);
         u &= 0xFFFF0000u;
         memcpy(&dst[e], &u, 4);
+      }
+      if (I % 64 == 0) {
+        l.oct = (O >= 8192 || I >= 4096) ? 8 : 1;  // wide (gate|up) and deep (down) matrices: 64 columns per workgroup
+        const int CB = 8 * l.oct, nblk = (O + CB - 1) / CB;
+        l.boff = m->packb.size();
+        m->packb.resize(l.boff + (size_t)nblk * I * CB, 0);
+        uint16_t* db = &m->packb[l.boff];
+        for (int i = 0; i < I; ++i)
+          for (int o = 0; o < O; ++o) {
+            uint32_t u;
+            memcpy(&u, &dst[(size_t)i * l.ldw + o], 4);
+            db[((size_t)(o / CB) * I + i) * CB + o % CB] = (uint16_t)(u >> 16);
+          }
       }
     }
     return l;
@@ -695,7 +981,7 @@ void pack_stack(Packer& P, const std::string& name, Stack& st, int max_pos) {
 
 void resolve(kk_csm* m, Lin& l) {
   l.w = m->dev + l.off;
-  l.wb = m->devb ? m->devb + l.boff : nullptr;
+  l.wb = (m->devb && l.oct) ? m->devb + l.boff : nullptr;
 }
 void resolve(kk_csm* m, Vec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_csm* m, Stack& st) {
@@ -722,7 +1008,7 @@ struct Run {
   // out[b][row][:] = W x[b][row][:] (+ res); x rows: `rows` per item at pitch `xbs` elements between items
   // `gated`: x is [.. rows][2 * Cin] = gate | up and the input of the product is silu(gate) * up (skinny bf16 path only; callers check
   // can_gate() first and run the stand-alone swiglu kernel otherwise).  `nw` / `xn`: RMSNorm of the result rows, launched right behind.
-  bool can_gate(const Lin& w, int rows) const { return w.wb && rows <= 2 && skinny_scratch != nullptr; }
+  bool can_gate(const Lin& w, int rows) const { (void)w; (void)rows; return false; }  // (the gated form lives in the fused GEMV now)
   int lin(const Lin& w, const float* x, long long xbs, int rows, float* out, long long obs, const float* res, bool gated = false,
           const float* nw = nullptr, float* xn = nullptr, float eps = 0.f) {
     if (dry) return 0;
@@ -740,7 +1026,7 @@ struct Run {
     if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && rows <= 2 && skinny_scratch) {
       // single-token steps (and the decoder's 2-token first step): the HBM-bound skinny GEMM (every CU streams a slice of W once for up
       // to 16 rows).  The choice depends on the rows PER ITEM only, never on B, so a stream's bits do not depend on its batch.
-      const int Mtot = B * rows, nblk256 = kk_cdiv(w.Cout, 256), nblk = w.wb ? kk_cdiv(w.Cout, 512) : nblk256;
+      const int Mtot = B * rows, nblk256 = kk_cdiv(w.Cout, 256), nblk = nblk256;
       int KS = 1024 / nblk256;  // ~4 workgroups per CU (measured: fewer, longer slices are slower -- the kernel is latency-bound)
       int maxks = kk_cdiv(w.Cin, 32);
       if (maxks > 128) maxks = 128;  // deep, narrow matrices (down projections: K = 8192, N = 1024 / 2048) need the slices to fill the chip
@@ -752,13 +1038,9 @@ struct Run {
           const int M = Mtot - m0 < SK_MAXM ? Mtot - m0 : SK_MAXM;
           const float* xin = x + (size_t)m0 * (gated ? 2 : 1) * w.Cin;
           const dim3 g(nblk, KS), t(256);
-#define SK_GO(MT, BW, GT) hipLaunchKernelGGL((skinny_gemm_kernel<MT, BW, GT>), g, t, 0, st, xin, M, w.Cin, BW ? (const void*)w.wb : (const void*)w.w, w.ldw, w.Cout, kchunk, skinny_scratch)
+#define SK_GO(MT) hipLaunchKernelGGL((skinny_gemm_kernel<MT, false, false>), g, t, 0, st, xin, M, w.Cin, (const void*)w.w, w.ldw, w.Cout, kchunk, skinny_scratch)
           // MT depends on the rows per launch only through "fits in 8": a row's arithmetic is the same in both instantiations
-          if (M <= 8) {
-            if (w.wb && gated) SK_GO(8, true, true); else if (w.wb) SK_GO(8, true, false); else SK_GO(8, false, false);
-          } else {
-            if (w.wb && gated) SK_GO(16, true, true); else if (w.wb) SK_GO(16, true, false); else SK_GO(16, false, false);
-          }
+          if (M <= 8) SK_GO(8); else SK_GO(16);
 #undef SK_GO
           KK_CHECK_LAUNCH();
           const float* resp = res ? res + (size_t)m0 * w.Cout : nullptr;
@@ -789,6 +1071,64 @@ struct Run {
     return 0;
   }
 };
+
+// fused GEMV launcher: `a` carries everything but the weights; rows in chunks of 16 (PRO 3: `rows` rows per item, chunk = whole items)
+// split-K slices of a deep projection (K >= 4096 on 64-column blocks): enough workgroups to fill the chip; depends on the matrix only
+int gemv_slices(const Lin& w) {
+  if (w.oct != 8 || w.Cin < 4096) return 1;
+  const int nblk = (w.Cout + 63) / 64;
+  int ks = 256 / nblk;
+  if (ks > 16) ks = 16;
+  while (ks > 1 && (w.Cin % ks != 0 || (w.Cin / ks) % 32 != 0)) --ks;
+  return ks < 1 ? 1 : ks;
+}
+int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st, int KS = 1) {
+  if (!w.wb || !w.oct) return kk_fail("kk_csm: internal: fused GEMV without a block pack");
+  a.w = w.wb; a.K = w.Cin; a.N = w.Cout;
+  const int CB = 8 * w.oct, nblk = (w.Cout + CB - 1) / CB;
+  if ((epi == 2) != (KS > 1 || epi == 2)) return kk_fail("kk_csm: internal: split-K form");
+  for (int m0 = 0; m0 < Mtot; m0 += 16) {
+    FGArgs g = a;
+    g.M = Mtot - m0 < 16 ? Mtot - m0 : 16;
+    if (pro == 3) {
+      const int item0 = m0 / a.rows;
+      g.x = a.x + (long long)item0 * a.xrs;
+      g.codes = a.codes + (long long)item0 * a.cstride;
+    } else {
+      g.x = a.x + (long long)m0 * a.xrs;
+    }
+    if (a.res) g.res = a.res + (long long)m0 * a.rrs;
+    g.out = a.out + (long long)m0 * a.ors;
+#define FG_GO(MT, OCT, PRO, EPI)                                                                                                        \
+  do {                                                                                                                                   \
+    static bool attr = false;                                                                                                            \
+    const size_t lds_ = (fg_lds_bytes<MT, OCT>());                                                                                       \
+    if (!attr) {                                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)fused_gemv_kernel<MT, OCT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                (int)lds_);                                                                                              \
+      attr = true;                                                                                                                       \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL((fused_gemv_kernel<MT, OCT, PRO, EPI>), dim3(nblk, KS), dim3(256), lds_, st, g);                                      \
+  } while (0)
+#define FG_PE(MT, OCT)                                                      \
+  do {                                                                       \
+    if (pro == 1 && epi == 0) FG_GO(MT, OCT, 1, 0);                          \
+    else if (pro == 0 && epi == 1) FG_GO(MT, OCT, 0, 1);                     \
+    else if (pro == 2 && epi == 1) FG_GO(MT, OCT, 2, 1);                     \
+    else if (pro == 2 && epi == 2) FG_GO(MT, OCT, 2, 2);                     \
+    else if (pro == 3 && epi == 0) FG_GO(MT, OCT, 3, 0);                     \
+    else if (pro == 0 && epi == 0) FG_GO(MT, OCT, 0, 0);                     \
+    else return kk_fail("kk_csm: internal: fused GEMV form");                \
+  } while (0)
+    // MT depends on the rows per launch only through "fits in 8": a row's arithmetic is the same in both instantiations
+    if (g.M <= 8) { if (w.oct == 8) FG_PE(8, 8); else FG_PE(8, 1); }
+    else { if (w.oct == 8) FG_PE(16, 8); else FG_PE(16, 1); }
+#undef FG_PE
+#undef FG_GO
+    KK_CHECK_LAUNCH();
+  }
+  return 0;
+}
 
 #define CS_TRY(x)          \
   do {                     \
@@ -821,13 +1161,13 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
     if (!r.dry) {
       if (S == 1) {  // single-token step: RoPE + cache append inside the attention kernel
         hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev,
-                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, st.rope.p);
+                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, st.rope.p, st.pad_dev);
         KK_CHECK_LAUNCH();
       } else {
-        hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos);
+        hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, r.st, qkv, S, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos, st.pad_dev);
         KK_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_cache_kernel<false>, dim3(S, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, S, H, KV, hd, st.pos_dev,
-                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, (const float*)nullptr);
+                           st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, (const float*)nullptr, st.pad_dev);
         KK_CHECK_LAUNCH();
       }
     }
@@ -847,6 +1187,67 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
         KK_CHECK_LAUNCH();
       }
       CS_TRY(r.lin(L.down, act, (long long)S * I, S, h, (long long)S * D, h, false, nw, xn, a.rms_eps));
+    }
+  }
+  return 0;
+}
+
+// The single-token step of a Llama stack in bf16 weight mode: FIVE launches per layer, no split-K partials, no stand-alone reduce / norm /
+// SwiGLU kernels -- qkv = W(rms(h) n1); attention (RoPE + cache append inside for one-row items); h += Wo att; gu = W(rms(h) n2);
+// h += Wdown(silu(gate) up).  h [B][rows][D] is updated in place; the consumer applies the final norm (a head's prologue).
+bool stack_can_step(const Stack& st) {
+  for (const auto& L : st.layers)
+    if (!(L.qkv.wb && L.o.wb && L.gu.wb && L.down.wb)) return false;
+  return !st.layers.empty();
+}
+int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
+  const kk_llama_args& a = st.a;
+  const int B = r.B, H = a.num_heads, KV = a.num_kv_heads, hd = a.head_dim, D = a.hidden, I = a.intermediate;
+  const int W = (H + 2 * KV) * hd, M = B * rows;
+  float* qkv = r.f32((size_t)M * W);
+  float* att = r.f32((size_t)M * H * hd);
+  float* gu = r.f32((size_t)M * 2 * I);
+  float* part = r.f32((size_t)16 * M * D);  // partial tiles of a split-K down projection (<= 16 slices)
+  if (r.oom) return kk_fail("kk_csm: workspace too small");
+  if (r.dry) return 0;
+  if (offset + rows > st.max_pos) return kk_fail("kk_csm: sequence exceeds the cache (max_seq_len)");
+  for (int l = 0; l < a.num_layers; ++l) {
+    const LlamaLayer& L = st.layers[l];
+    float* kc = st.kc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
+    float* vc = st.vc + (size_t)l * r.m->max_batch * st.max_pos * KV * hd;
+    FGArgs g;
+    memset(&g, 0, sizeof g);
+    g.x = h; g.xrs = D; g.nw = L.n1.p; g.eps = a.rms_eps; g.out = qkv; g.ors = W;
+    CS_TRY(launch_gemv(L.qkv, 1, 0, g, M, r.st));
+    if (rows == 1) {
+      hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(1, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, 1, H, KV, hd, st.pos_dev,
+                         st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, st.rope.p, st.pad_dev);
+      KK_CHECK_LAUNCH();
+    } else {
+      hipLaunchKernelGGL(rope_append_kernel, dim3(rows, B), dim3(256), 0, r.st, qkv, rows, H, KV, hd, st.rope.p, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc,
+                         st.max_pos, st.pad_dev);
+      KK_CHECK_LAUNCH();
+      hipLaunchKernelGGL(attn_cache_kernel<false>, dim3(rows, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, rows, H, KV, hd, st.pos_dev,
+                         st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, (const float*)nullptr, st.pad_dev);
+      KK_CHECK_LAUNCH();
+    }
+    memset(&g, 0, sizeof g);
+    g.x = att; g.xrs = (long long)H * hd; g.res = h; g.rrs = D; g.out = h; g.ors = D;
+    CS_TRY(launch_gemv(L.o, 0, 1, g, M, r.st));
+    memset(&g, 0, sizeof g);
+    g.x = h; g.xrs = D; g.nw = L.n2.p; g.eps = a.rms_eps; g.out = gu; g.ors = 2 * I;
+    CS_TRY(launch_gemv(L.gu, 1, 0, g, M, r.st));
+    memset(&g, 0, sizeof g);
+    const int KS = gemv_slices(L.down);
+    if (KS > 1) {  // deep projection: K slices over workgroups, then one small combine (h += sum of the slices)
+      g.x = gu; g.xrs = 2 * I; g.out = part; g.ors = D; g.pss = (long long)M * D;
+      CS_TRY(launch_gemv(L.down, 2, 2, g, M, r.st, KS));
+      const long long n = (long long)M * D;
+      hipLaunchKernelGGL(combine_slices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, part, KS, n, n, h);
+      KK_CHECK_LAUNCH();
+    } else {
+      g.x = gu; g.xrs = 2 * I; g.res = h; g.rrs = D; g.out = h; g.ors = D;
+      CS_TRY(launch_gemv(L.down, 2, 1, g, M, r.st));
     }
   }
   return 0;
@@ -873,17 +1274,66 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
     KK_CHECK_LAUNCH();
   }
   const size_t inner = r.used;
-  CS_TRY(stack_forward(r, m->bb, h, S, m->bb.offset, hn));
+  // bf16 weight mode: single-token frames (and every depth-decoder step) run on the fused five-launch layers
+  const bool fast = m->wdt == KK_BF16 && stack_can_step(m->bb) && stack_can_step(m->dec) && m->proj.wb && m->c0_head.wb;
+  bool heads_fast = fast;
+  for (const auto& l : m->audio_head) heads_fast = heads_fast && l.wb;
+  const float* last_h;   // the backbone's final-normed last position of every item
+  long long last_rs;     // its item pitch
+  if (fast && heads_fast && S == 1) {
+    CS_TRY(stack_step(r, m->bb, h, 1, m->bb.offset));
+    if (!r.dry) {
+      hipLaunchKernelGGL(rmsnorm_kernel, dim3(B), dim3(256), 0, r.st, h, m->bb.norm.p, D, c.backbone.rms_eps, hn);
+      KK_CHECK_LAUNCH();
+    }
+    last_h = hn; last_rs = D;
+  } else {
+    CS_TRY(stack_forward(r, m->bb, h, S, m->bb.offset, hn));
+    last_h = hn ? hn + (size_t)(S - 1) * D : nullptr;  // row S-1 of every item (pitch S*D)
+    last_rs = (long long)S * D;
+  }
   size_t peak = r.used;
   r.used = inner;  // the stack's scratch is free again
-  const float* last_h = hn ? hn + (size_t)(S - 1) * D : nullptr;  // row S-1 of every item (pitch S*D)
   // the heads write their logits straight into the slot kk_csm_debug_logits reads ([n_cb][maxB][V], first B rows): no copy per code book
   if (!r.dry && m->dbg_logits) logits = m->dbg_logits;
-  CS_TRY(r.lin(m->c0_head, last_h, (long long)S * D, 1, logits, V, nullptr));
+  if (fast && heads_fast) {
+    if (!r.dry) {
+      FGArgs g;
+      memset(&g, 0, sizeof g);
+      g.x = last_h; g.xrs = last_rs; g.out = logits; g.ors = V;
+      CS_TRY(launch_gemv(m->c0_head, 0, 0, g, B, r.st));
+      CS_TRY(launch_sample(logits, V, temp, top_k, uniforms, ncb, codes, ncb, B, r.st));
+    }
+    int rows = 2, dpos = 0;
+    for (int i = 1; i < ncb; ++i) {
+      r.used = inner;
+      // curr = [last_h, embed(0, c0)] for the first step, [embed(i-1, c_{i-1})] afterwards (sesame.py:373-392): gathered by the projection's prologue
+      if (!r.dry) {
+        FGArgs g;
+        memset(&g, 0, sizeof g);
+        g.x = last_h; g.xrs = last_rs; g.codes = codes + (i - 1); g.cstride = ncb; g.cb = i - 1; g.V = V; g.rows = rows; g.emb = m->audio_emb.p;
+        g.out = pin; g.ors = Dd;
+        CS_TRY(launch_gemv(m->proj, 3, 0, g, B * rows, r.st));
+      }
+      CS_TRY(stack_step(r, m->dec, pin, rows, dpos));
+      if (r.used > peak) peak = r.used;
+      dpos += rows;
+      if (!r.dry) {
+        if (m->dbg_logits) logits = m->dbg_logits + (size_t)i * m->max_batch * V;
+        FGArgs g;
+        memset(&g, 0, sizeof g);
+        g.x = pin + (size_t)(rows - 1) * Dd; g.xrs = (long long)rows * Dd; g.nw = m->dec.norm.p; g.eps = c.decoder.rms_eps; g.out = logits; g.ors = V;
+        CS_TRY(launch_gemv(m->audio_head[i - 1], 1, 0, g, B, r.st));
+        CS_TRY(launch_sample(logits, V, temp, top_k, uniforms ? uniforms + i : nullptr, ncb, codes + i, ncb, B, r.st));
+      }
+      rows = 1;
+    }
+  } else {
+  CS_TRY(r.lin(m->c0_head, last_h, last_rs, 1, logits, V, nullptr));
   if (!r.dry) {
     CS_TRY(launch_sample(logits, V, temp, top_k, uniforms, ncb, codes, ncb, B, r.st));
     // curr = [last_h, embed_audio(0, c0)]
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(B), dim3(256), 0, r.st, last_h, (long long)S * D, curr, (long long)2 * D, D);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(B), dim3(256), 0, r.st, last_h, last_rs, curr, (long long)2 * D, D);
     KK_CHECK_LAUNCH();
     hipLaunchKernelGGL(embed_audio_kernel, dim3(B), dim3(256), 0, r.st, codes, ncb, m->audio_emb.p, 0, V, D, curr, 2, 1);
     KK_CHECK_LAUNCH();
@@ -904,6 +1354,7 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
       KK_CHECK_LAUNCH();
     }
     rows = 1;
+  }
   }
   if (!r.dry) {
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, r.st, m->bb.pos_dev, S);
@@ -927,7 +1378,7 @@ int check_llama(const kk_llama_args& a) {
 // table on q (in place) and k, k / v appended to the caches at `offset`; attention of the S new queries over the cache
 int kk_launch_rope_append(float* qkv, int S, int H, int KV, int hd, const float* rope, int offset, float* kc, float* vc, int max_pos, int B, hipStream_t st) {
   if (hd != 64 && hd != 128) return kk_fail("rope_append: head_dim must be 64 or 128");
-  hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, st, qkv, S, H, KV, hd, rope, (const int*)nullptr, offset, kc, vc, max_pos);
+  hipLaunchKernelGGL(rope_append_kernel, dim3(S, B), dim3(256), 0, st, qkv, S, H, KV, hd, rope, (const int*)nullptr, offset, kc, vc, max_pos, (const int*)nullptr);
   KK_CHECK_LAUNCH();
   return 0;
 }
@@ -935,7 +1386,7 @@ int kk_launch_attn_cache(const float* qkv, int S, int H, int KV, int hd, int off
                          int causal, int ctx, int B, hipStream_t st) {
   if (hd != 64 && hd != 128) return kk_fail("attn_cache: head_dim must be 64 or 128");
   hipLaunchKernelGGL(attn_cache_kernel<false>, dim3(S, H, B), dim3(128), attn_lds_bytes(max_pos, hd), st, qkv, S, H, KV, hd, (const int*)nullptr, offset,
-                     const_cast<float*>(kc), const_cast<float*>(vc), max_pos, scale, out, causal, ctx, (const float*)nullptr);
+                     const_cast<float*>(kc), const_cast<float*>(vc), max_pos, scale, out, causal, ctx, (const float*)nullptr, (const int*)nullptr);
   KK_CHECK_LAUNCH();
   return 0;
 }
@@ -970,6 +1421,7 @@ extern "C" void kk_csm_destroy(kk_csm* m) {
   }
   if (m->dbg_logits) (void)hipFree(m->dbg_logits);
   if (m->bb.pos_dev) (void)hipFree(m->bb.pos_dev);
+  if (m->bb.pad_dev) (void)hipFree(m->bb.pad_dev);
   for (auto& g : m->graphs) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (g.graph) (void)hipGraphDestroy(g.graph);
@@ -1061,7 +1513,22 @@ extern "C" int kk_csm_setup_caches(kk_csm* m, int max_batch) {
     return kk_fail("kk_csm_setup_caches: hipMalloc failed");
   if (!m->bb.pos_dev && hipMalloc((void**)&m->bb.pos_dev, 4) != hipSuccess) return kk_fail("kk_csm_setup_caches: hipMalloc failed");
   if (hipMemset(m->bb.pos_dev, 0, 4) != hipSuccess) return kk_fail("kk_csm_setup_caches: memset failed");
+  if (m->bb.pad_dev) (void)hipFree(m->bb.pad_dev);
+  m->bb.pad_dev = nullptr;
+  if (hipMalloc((void**)&m->bb.pad_dev, (size_t)max_batch * 4) != hipSuccess || hipMemset(m->bb.pad_dev, 0, (size_t)max_batch * 4) != hipSuccess)
+    return kk_fail("kk_csm_setup_caches: hipMalloc failed");
   m->max_batch = max_batch;
+  return 0;
+}
+// Ragged prompts: the streams of a batch are LEFT-padded to the longest prompt (padding frames carry an all-zero mask); pad[b] = number of
+// padding frames of item b.  Item b's token in cache slot p then has position p - pad[b] (RoPE) and sees the slots >= pad[b] only, so its
+// results are bit-identical to running it alone.  Call on an empty cache (after setup / reset), before the prompt block; reset clears it.
+extern "C" int kk_csm_set_padding(kk_csm* m, int B, const int32_t* pad_host) {
+  if (!m || !m->bb.pad_dev || B < 1 || B > m->max_batch || !pad_host) return kk_fail("kk_csm_set_padding: bad argument (call kk_csm_setup_caches first)");
+  if (m->bb.offset != 0) return kk_fail("kk_csm_set_padding: the cache is not empty");
+  for (int b = 0; b < B; ++b)
+    if (pad_host[b] < 0 || pad_host[b] >= m->bb.max_pos) return kk_fail("kk_csm_set_padding: padding out of range");
+  if (hipMemcpy(m->bb.pad_dev, pad_host, (size_t)B * 4, hipMemcpyHostToDevice) != hipSuccess) return kk_fail("kk_csm_set_padding: copy failed");
   return 0;
 }
 extern "C" int kk_csm_reset_caches(kk_csm* m) {
@@ -1069,6 +1536,7 @@ extern "C" int kk_csm_reset_caches(kk_csm* m) {
   m->bb.offset = 0;
   m->dec.offset = 0;
   if (m->bb.pos_dev && hipMemset(m->bb.pos_dev, 0, 4) != hipSuccess) return kk_fail("kk_csm_reset_caches: memset failed");
+  if (m->bb.pad_dev && hipMemset(m->bb.pad_dev, 0, (size_t)m->max_batch * 4) != hipSuccess) return kk_fail("kk_csm_reset_caches: memset failed");
   return 0;
 }
 extern "C" int kk_csm_position(const kk_csm* m) { return m ? m->bb.offset : -1; }

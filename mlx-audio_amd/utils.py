@@ -11,7 +11,7 @@ import logging
 from pathlib import Path
 from typing import Union
 
-MODEL_REMAPPING = {"kokoro": "kokoro"}
+MODEL_REMAPPING = {"kokoro": "kokoro", "csm": "sesame", "sesame": "sesame"}  # (tts/utils.py:17-22 maps "csm" to the sesame package)
 
 
 def get_model_path(path_or_hf_repo: str, revision=None) -> Path:
@@ -34,18 +34,22 @@ def load_config(model_path: Union[str, Path]) -> dict:
 
 
 def get_model_and_args(model_type: str, model_name):
-    """utils.py:77-121: only the Kokoro path exists in this engine."""
+    """utils.py:77-121: the model families this engine serves: kokoro and sesame (CSM); anything else raises like the reference."""
     model_type = MODEL_REMAPPING.get(model_type, model_type)
     for part in model_name or []:
         if part in MODEL_REMAPPING:
             model_type = MODEL_REMAPPING[part]
-    if model_type != "kokoro":
-        msg = f"Model type {model_type} not supported."
-        logging.error(msg)
-        raise ValueError(msg)
-    from . import kokoro
+    if model_type == "kokoro":
+        from . import kokoro
 
-    return kokoro, model_type
+        return kokoro, model_type
+    if model_type == "sesame":
+        from . import sesame
+
+        return sesame, model_type
+    msg = f"Model type {model_type} not supported."
+    logging.error(msg)
+    raise ValueError(msg)
 
 
 def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtype: str = None, quantization_kernel: str = "exact", **kwargs):
@@ -84,6 +88,12 @@ def load_model(model_path, lazy: bool = False, strict: bool = True, compute_dtyp
 
         any_bf16 = any(getattr(v, "dtype", None) == torch.bfloat16 for v in weights.values())
         compute_dtype = "bfloat16" if any_bf16 else "float32"  # the checkpoint dtype decides, as in the reference
+    if model_type == "sesame":
+        # sesame.Model(config) has no ModelConfig (tts/utils.py:226-230 passes the dict); the checkpoint dtype picks the weight storage
+        model = arch.Model(dict(config, **{k: v for k, v in kwargs.items() if k in ("mimi_path", "text_tokenizer")}),
+                           weight_dtype="bfloat16" if compute_dtype == "bfloat16" else "float32", mimi=kwargs.get("mimi"))
+        model.load_weights(weights, strict=strict)
+        return model
     quantization = config.get("quantization", None)
     if quantization is not None:  # utils.py:241-260: MLX affine group quantisation -> dequantised here, see quant.py
         import numpy as np

@@ -236,10 +236,12 @@ def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
     loop = Model(model, mimi)
     rng = np.random.default_rng(9)
     ref_audio = [(0.3 * rng.standard_normal(1920 * 3)).astype(np.float32) for _ in range(2)]
-    ctx = [[Segment(speaker=0, text_ids=rng.integers(0, 300, 5).tolist(), audio=ref_audio[b])] for b in range(2)]
+    ctx = [[Segment(speaker=0, text=rng.integers(0, 300, 5).tolist(), audio=ref_audio[b])] for b in range(2)]
     prompts = [rng.integers(0, 300, 4).tolist() for _ in range(2)]
-    res = loop.generate(ctx, prompts, max_audio_length_ms=80 * 6, temperature=0.0, stop_on_eos=False)
-    assert res.token_count == 6 and tuple(res.audio.shape) == (2, 6 * 1920) and bool(torch.isfinite(res.audio).all())
+    res = loop.generate_batch([loop.prompt_frames(ctx[b], prompts[b], 0, voice_match=False) for b in range(2)], max_audio_length_ms=80 * 6,
+                              temperature=0.0, stop_on_eos=False)
+    audio = torch.stack(res.audio)
+    assert res.frames == [6, 6] and tuple(audio.shape) == (2, 6 * 1920) and bool(torch.isfinite(audio).all())
     # oracle loop
     morc = MO.MimiOracle(mw, mcfg)
     corc = C.CsmOracle(cw, ccfg)
@@ -249,7 +251,7 @@ def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
         codes = morc.encode(ref_audio[b][None, None])[0]
         codes = np.concatenate([codes, np.zeros((n, 1), codes.dtype)], 1)
         rows = []
-        for ids in (ctx[b][0].text_ids,):
+        for ids in (ctx[b][0].text,):
             f = np.zeros((len(ids), n + 1), np.int64); f[:, -1] = ids
             m = np.zeros((len(ids), n + 1), np.float32); m[:, -1] = 1
             rows.append((f, m))
@@ -270,17 +272,123 @@ def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
         m_in = np.zeros((2, 1, n + 1), np.float32); m_in[:, 0, :n] = 1
     ref_codes = np.stack(frames, 2)
     ref_pcm = morc.decode(ref_codes)[:, 0]
-    e = err_stats(res.audio.cpu().numpy(), ref_pcm)
+    e = err_stats(audio.cpu().numpy(), ref_pcm)
     report("csm/e2e_tiny/pcm", **e)
     assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), e
     # stream=True (sesame.py:689-817 with generate_result(stream=True), :619-629): the same frames in partial results of
     # int(streaming_interval * 12.5) frames, decoded incrementally -- against the STREAMING Mimi oracle on the oracle loop's codes
     parts = list(loop.generate_stream(ctx, prompts, max_audio_length_ms=80 * 6, temperature=0.0, stop_on_eos=False, streaming_interval=0.2))
-    assert [p.token_count for p in parts] == [2, 2, 2] and all(tuple(p.audio.shape) == (2, 2 * 1920) for p in parts)
+    assert [p.frames for p in parts] == [[2, 2]] * 3 and all(tuple(torch.stack(p.audio).shape) == (2, 2 * 1920) for p in parts)
     ref_stream = MO.MimiStreamOracle(mw, mcfg).decode_frames(ref_codes)[:, 0]
-    es = err_stats(torch.cat([p.audio for p in parts], dim=1).cpu().numpy(), ref_stream)
+    es = err_stats(torch.cat([torch.stack(p.audio) for p in parts], dim=1).cpu().numpy(), ref_stream)
     report("csm/e2e_tiny/pcm_stream", **es)
     assert es["max_abs"] <= 1e-3 * max(1.0, es["ref_max"]), es
+
+
+@pytest.mark.parametrize("wdt", ["float32", "bfloat16"])
+def test_csm_ragged_prompts_in_one_batch_equal_single_stream_runs_bitexact(wdt):
+    """Streams whose prompts differ in length share a batch (left padding + per-item positions, kk_csm_set_padding): the prompt block, the
+    greedy and the sampled frames of every stream carry the bits of the stream's own B = 1 run, and so do the decoded waveforms; per-stream
+    EOS: a stream that ends early is trimmed to its own frames while the others go on."""
+    from mlx_audio_amd.csm import SesameModel
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+    from mlx_audio_amd.sesame import Model, Segment
+
+    ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
+    mcfg = P.mimi_tiny_config()
+    cw = P.csm_synth_checkpoint(ccfg, 3)
+    if wdt == "bfloat16":
+        cw = _as_bf16_checkpoint(cw)
+    mimi = Mimi(MimiConfig.from_dict(mcfg), P.mimi_synth_checkpoint(mcfg, 3, encode=True))
+    loop = Model(ccfg, mimi=mimi, weights=cw, weight_dtype=wdt)
+    rng = np.random.default_rng(19)
+    n = 4
+    ctxs, texts = [], []
+    for b, (na, nt) in enumerate(((3, 4), (1, 9), (5, 2))):  # prompt lengths 5+na+1+nt: 13, 16, 13 ... with audio of different lengths
+        audio = (0.3 * rng.standard_normal(1920 * na)).astype(np.float32)
+        ctxs.append([Segment(speaker=b, text=rng.integers(0, 300, 5).tolist(), audio=audio)])
+        texts.append(rng.integers(0, 300, nt).tolist())
+    prompts = [loop.prompt_frames(ctxs[b], texts[b], b, voice_match=(b == 1)) for b in range(3)]
+    assert len({p[0].shape[0] for p in prompts}) > 1
+    kw = dict(max_audio_length_ms=80 * 7, temperature=0.8, top_k=20, stop_on_eos=False)
+    # per-stream uniforms must match between the batched and the single runs: draw them per stream from the same seed by running B = 1
+    singles = []
+    for b in range(3):
+        singles.append(loop.generate_batch([prompts[b]], seed=100 + b, **kw))
+    rngs = [np.random.default_rng(100 + b) for b in range(3)]
+    both = loop.generate_batch(prompts, uniforms=lambda i: np.stack([r.uniform(size=(1, n))[0] for r in rngs]), **kw)
+    assert both.frames == [7, 7, 7]
+    for b in range(3):
+        np.testing.assert_array_equal(both.codes[b].cpu().numpy(), singles[b].codes[0].cpu().numpy())
+        assert torch.equal(both.audio[b], singles[b].audio[0])
+
+
+def test_csm_model_generate_surface_voice_match_and_stream():
+    """Model.generate (sesame.py:689-817) with pre-tokenised text: ref_audio / ref_text -> one context segment; voice_match (default) joins the
+    context text with the prompt and continues the context audio without an EOS frame; one GenerationResult per prompt; stream=True yields
+    partial results whose concatenation has the same number of samples."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+    from mlx_audio_amd.sesame import Model
+
+    ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
+    mcfg = P.mimi_tiny_config()
+    mimi = Mimi(MimiConfig.from_dict(mcfg), P.mimi_synth_checkpoint(mcfg, 3, encode=True))
+    loop = Model(ccfg, mimi=mimi, weights=P.csm_synth_checkpoint(ccfg, 3))
+    rng = np.random.default_rng(29)
+    ref = (0.3 * rng.standard_normal(1920 * 3)).astype(np.float32)
+    ref_ids, prompts = rng.integers(0, 300, 5).tolist(), [rng.integers(0, 300, 6).tolist(), rng.integers(0, 300, 3).tolist()]
+    with pytest.raises(ValueError):
+        list(loop.generate("a string needs a tokenizer", ref_audio=ref, ref_text=ref_ids))
+    with pytest.raises(FileNotFoundError):
+        list(loop.generate(prompts[0]))  # no context, no ref audio: the default speaker prompt would be downloaded
+    res = list(loop.generate(prompts, ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, temperature=0.0, stop_on_eos=False))
+    assert len(res) == 2 and all(r.token_count == 5 and r.samples == 5 * 1920 and r.sample_rate == 24000 for r in res)
+    f, m = loop.prompt_frames([type("S", (), dict(speaker=0, text=ref_ids, audio=ref))()], prompts[0], 0, voice_match=True)
+    assert f.shape[0] == len(ref_ids) + len(prompts[0]) + 3 and m[-1, :4].all()  # text ids of both, then the 3 audio frames, no EOS frame
+    parts = list(loop.generate(prompts[0], ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, temperature=0.0, stop_on_eos=False,
+                               stream=True, streaming_interval=0.16))
+    assert [p.token_count for p in parts] == [2, 2, 1] and sum(p.samples for p in parts) == res[0].samples
+
+
+def test_load_model_routes_sesame_checkpoints(tmp_path):
+    """load_model on a directory whose config.json says model_type "sesame" (or whose name carries csm: tts/utils.py:17-22,77-121) builds
+    sesame.Model: torchtune-style checkpoint names are sanitised (sesame.py:543-569), the codec comes from config["mimi_path"], and the
+    frames equal those of a model built directly from the same weights."""
+    import json
+
+    from safetensors.numpy import save_file
+
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+    from mlx_audio_amd.sesame import Model
+    from mlx_audio_amd.utils import load_model
+
+    ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
+    mcfg = P.mimi_tiny_config()
+    cw = P.csm_synth_checkpoint(ccfg, 3)
+    mw = P.mimi_synth_checkpoint(mcfg, 3, encode=True)
+
+    def torchtune(k):  # the names `sanitize` converts FROM
+        k = k.replace("self_attn.o_proj", "attn.output_proj").replace("self_attn", "attn")
+        k = k.replace("gate_proj", "w1").replace("down_proj", "w2").replace("up_proj", "w3")
+        k = k.replace("input_layernorm.weight", "sa_norm.scale").replace("post_attention_layernorm.weight", "mlp_norm.scale")
+        return k.replace("backbone.norm.weight", "backbone.norm.scale").replace("decoder.norm.weight", "decoder.norm.scale")
+
+    d = tmp_path / "csm-tiny"
+    d.mkdir()
+    md = tmp_path / "mimi"
+    md.mkdir()
+    save_file({k: np.ascontiguousarray(v) for k, v in mw.items()}, str(md / "model.safetensors"))
+    json.dump(mcfg, open(md / "config.json", "w"))  # (a tiny codec: the default would be mimi_202407)
+    save_file({torchtune(k): np.ascontiguousarray(v) for k, v in cw.items()}, str(d / "model.safetensors"))
+    json.dump(dict(ccfg, model_type="sesame", mimi_path=str(md)), open(d / "config.json", "w"))
+    model = load_model(str(d))
+    assert isinstance(model, Model) and model.sample_rate == 24000 and model._audio_tokenizer.cfg.nq == 4
+    direct = Model(ccfg, mimi=Mimi(MimiConfig.from_dict(dict(mcfg)), mw), weights=cw)
+    rng = np.random.default_rng(2)
+    ref, ids, prompt = (0.3 * rng.standard_normal(1920 * 2)).astype(np.float32), rng.integers(0, 300, 4).tolist(), rng.integers(0, 300, 5).tolist()
+    kw = dict(ref_audio=ref, ref_text=ids, max_audio_length_ms=80 * 4, temperature=0.0, stop_on_eos=False)
+    a, b = list(model.generate(prompt, **kw)), list(direct.generate(prompt, **kw))
+    assert len(a) == 1 and torch.equal(a[0].audio, b[0].audio)
 
 
 def test_csm_golden_fixture_without_oracle():

@@ -281,3 +281,66 @@ def test_tts_service_request_semantics_and_pool_planner():
     f = svc.submit("", speed="1.0")
     assert f.done() and isinstance(f.exception(), TTSError) and f.exception().status == 400
     assert svc._q.empty()
+
+
+def test_csm_generate_batch_tracks_every_streams_own_eos():
+    """sesame.Model.generate_batch on a scripted frame generator (no GPU): an all-zero frame ends a stream (sesame.py:765-766); streams that
+    end early are trimmed to their own frames, the loop runs until the LAST stream has ended (checked every `eos_check_interval` frames),
+    ragged prompts are left-padded and announced to the model, and sampling draws fresh uniforms when seed is None."""
+    import torch
+
+    from mlx_audio_amd.sesame import Model
+
+    class FakeCsm:
+        cfg = dict(audio_num_codebooks=2, max_seq_len=64)
+        device = torch.device("cpu")
+        max_batch = 0
+
+        def __init__(self):
+            self.calls, self.pads, self.uniforms = [], None, []
+            self.script = {0: 5, 1: 2, 2: 9}  # stream b emits its all-zero frame at frame index script[b]
+
+        def caches_are_enabled(self):
+            return self.max_batch > 0
+
+        def setup_caches(self, B):
+            self.max_batch = B
+
+        def reset_caches(self):
+            self.frame = 0
+
+        def set_padding(self, pads):
+            self.pads = list(pads)
+
+        def set_graph_mode(self, on):
+            pass
+
+        def generate_frame(self, tok, msk, temperature=0.0, top_k=50, uniforms=None):
+            self.calls.append(tuple(tok.shape))
+            self.uniforms.append(None if uniforms is None else uniforms.clone())
+            out = torch.full((tok.shape[0], 2), 7, dtype=torch.int32)
+            for b, at in self.script.items():
+                if self.frame == at:
+                    out[b] = 0
+            self.frame += 1
+            return out
+
+    class FakeMimi:
+        def decode(self, codes):
+            return torch.arange(codes.shape[0] * codes.shape[2] * 1920, dtype=torch.float32).reshape(codes.shape[0], 1, -1)
+
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        csm = FakeCsm()
+        m = Model(dict(csm.cfg, backbone={}, decoder={}, text_vocab_size=10, audio_vocab_size=10), mimi=FakeMimi(), csm=csm)
+        prompts = [(np.ones((L, 3), np.int32), np.ones((L, 3), np.float32)) for L in (4, 6, 5)]
+        res = m.generate_batch(prompts, max_audio_length_ms=80 * 40, temperature=0.9, seed=None, eos_check_interval=4)
+    finally:
+        torch.cuda.synchronize = real_sync
+    assert csm.pads == [2, 0, 1] and csm.calls[0] == (3, 6, 3) and set(csm.calls[1:]) == {(3, 1, 3)}
+    assert res.frames == [5, 2, 9] and [a.shape[0] for a in res.audio] == [5 * 1920, 2 * 1920, 9 * 1920]
+    assert len(csm.calls) == 12  # the last EOS is frame 9; the host looks every 4 frames: 12 frames were generated, 3 dropped
+    assert res.codes.shape == (3, 2, 9)
+    u = [x for x in csm.uniforms if x is not None]
+    assert len(u) == 12 and not torch.equal(u[0], u[1])  # seed=None still SAMPLES (fresh entropy), it does not fall back to argmax

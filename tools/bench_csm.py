@@ -39,14 +39,14 @@ if a.e2e:
     mimi = Mimi(mimi_202407(32), P.mimi_synth_checkpoint(mcfg, 0, encode=True), compute_dtype="bfloat16")
     loop = Model(model, mimi)
     ref = [(0.1 * rng.standard_normal(24000 * 2)).astype(np.float32) for _ in range(B)]  # 2 s of reference audio per stream
-    ctx = [[Segment(speaker=0, text_ids=rng.integers(0, cfg["text_vocab_size"], 24).tolist(), audio=ref[b])] for b in range(B)]
-    prompts = [rng.integers(0, cfg["text_vocab_size"], 24).tolist() for _ in range(B)]
-    loop.generate(ctx, prompts, max_audio_length_ms=80 * 3, stop_on_eos=False)  # warm-up
-    res = loop.generate(ctx, prompts, max_audio_length_ms=80 * a.frames, stop_on_eos=False)
-    secs = res.samples / 24000.0
+    ctx = [[Segment(speaker=0, text=rng.integers(0, cfg["text_vocab_size"], 24).tolist(), audio=ref[b])] for b in range(B)]
+    prompts = [loop.prompt_frames(ctx[b], rng.integers(0, cfg["text_vocab_size"], 24).tolist(), 0, voice_match=False) for b in range(B)]
+    loop.generate_batch(prompts, max_audio_length_ms=80 * 3, stop_on_eos=False)  # warm-up
+    res = loop.generate_batch(prompts, max_audio_length_ms=80 * a.frames, stop_on_eos=False)
+    secs = res.audio[0].shape[0] / 24000.0
     print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B end to end: reference-audio prompt (Mimi.encode) + text ids -> frames -> Mimi.decode",
                       "value": B * secs / res.processing_time_seconds, "wall_s": res.processing_time_seconds, "audio_s_per_stream": secs, "batch": B,
-                      "frames": res.token_count, "prompt_frames": 24 + 26 + 24, "dtype": ("bf16-weight" if a.weights == "bfloat16" else "f32") + " frame generator, fp32 Mimi.encode, bf16 Mimi.decode",
+                      "frames": res.frames[0], "prompt_frames": 24 + 26 + 24, "dtype": ("bf16-weight" if a.weights == "bfloat16" else "f32") + " frame generator, fp32 Mimi.encode, bf16 Mimi.decode",
                       "data": "synthetic (random-init weights, random token ids, noise reference audio, EOS ignored)",
                       "setup_s": {"synth_checkpoint": round(t1 - t0, 1), "load_finalize": round(t2 - t1, 1)}}))
     sys.exit(0)
