@@ -122,6 +122,10 @@ def main():
                     help="with --quantized: 'exact' (default) = the dequantised weights scale*q+bias on the bf16 MFMA kernels, the reference's arithmetic "
                          "(tts/utils.py:241-260); 'mxfp8' = the opt-in e4m3 kernels.  The other one is measured too and reported next to `value`.")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
+    ap.add_argument("--config", default="kokoro", choices=["kokoro", "csm"],
+                    help="kokoro (default): BASELINE configs[1], the headline.  csm: configs[3], CSM-1B + Mimi at the SURVEY 8(d) pin -- B = 8 streams, each a "
+                         "10 s reference-audio prompt (125 Mimi frames) + 64 text ids, 125 frames generated greedily, Mimi decode included; a step is one "
+                         "whole generation.")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU (gloo): rendezvous, barrier, MAX reduction, rank 0's line")
     args = ap.parse_args()
 
@@ -138,6 +142,15 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
+    if args.config == "csm":
+        out = bench_csm(args, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            import torch.distributed as dist_mod
+
+            dist_mod.destroy_process_group()
+        return
     out = bench_kokoro(args, rank, world)
     if args.quantized:  # (every rank: the second configuration has the same collectives)
         # config 5 reports BOTH arithmetic choices for the quantised layer set: the default ("exact": dequantised weights, bf16 activations -- the
@@ -153,6 +166,136 @@ def main():
         import torch.distributed as dist_mod
 
         dist_mod.destroy_process_group()
+
+
+def bench_csm(args, rank, world):
+    """BASELINE configs[3] at the SURVEY 8(d) pin.  Replicas only: the streams of a batch are independent and there is no exchange step, every
+    rank runs its own B = 8 batch; `value` is the aggregate."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    import mlx_audio_amd.params as P
+    from mlx_audio_amd.mimi import Mimi, mimi_202407
+    from mlx_audio_amd.sesame import Model, Segment
+
+    B, REF_S, N_TEXT, FRAMES = (args.batch if args.batch != BATCH_PER_GPU else 8), 10.0, 64, 125
+    cfg = P.csm_config()
+    w = P.csm_synth_checkpoint(cfg, 0)
+    mcfg = P.mimi_config(32)
+    mw = P.mimi_synth_checkpoint(mcfg, 0, encode=True)
+    mimi = Mimi(mimi_202407(32), mw, compute_dtype="bfloat16")
+    model = Model(cfg, mimi=mimi, weights=w, weight_dtype="bfloat16")  # a bf16 checkpoint: matrices stored / streamed as bf16, fp32 arithmetic
+    rng = np.random.default_rng(1000 + rank)
+    ctx, texts = [], []
+    for b in range(B):
+        ref = (0.1 * rng.standard_normal(int(24000 * REF_S))).astype(np.float32)
+        ctx.append([Segment(speaker=0, text=rng.integers(0, cfg["text_vocab_size"], N_TEXT // 2).tolist(), audio=ref)])
+        texts.append(rng.integers(0, cfg["text_vocab_size"], N_TEXT // 2).tolist())
+
+    def step():
+        # the whole job: reference audio -> Mimi.encode -> prompt frames -> prompt block -> FRAMES frames (greedy: deterministic) -> Mimi.decode
+        prompts = [model.prompt_frames(ctx[b], texts[b], 0, voice_match=False) for b in range(B)]
+        return model.generate_batch(prompts, max_audio_length_ms=80 * FRAMES, temperature=0.0, stop_on_eos=False), prompts[0][0].shape[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        res, S = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, S = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # the frame step on its own, HIP events on the stream the frames are launched on (torch's current stream): FRAMES single-token frames
+    csm = model.model
+    n = cfg["audio_num_codebooks"]
+    tok = torch.zeros((B, 1, n + 1), dtype=torch.int32, device=csm.device)
+    msk = torch.zeros((B, 1, n + 1), dtype=torch.float32, device=csm.device)
+    msk[:, 0, :n] = 1
+    for _ in range(3):
+        codes = csm.generate_frame(tok, msk)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nfr = 50
+    e0.record()
+    for _ in range(nfr):
+        codes = csm.generate_frame(tok, msk)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_frame = e0.elapsed_time(e1) / nfr
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=csm.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def lin(a):  # parameters of one Llama layer's linears (attention.py / mlx_lm LlamaModel: q, k, v, o, gate, up, down)
+        H, KV, hd, D, I = a["num_heads"], a["num_kv_heads"], a["head_dim"], a["hidden"], a["intermediate"]
+        return D * (H + 2 * KV) * hd + H * hd * D + 3 * D * I
+
+    bb, dc, V, D, Dd = cfg["backbone"], cfg["decoder"], cfg["audio_vocab_size"], cfg["backbone"]["hidden"], cfg["decoder"]["hidden"]
+    # algorithmic bytes of one frame: every Linear matrix it multiplies by, once per use, in the checkpoint's bf16 (sesame.py:349-395: the
+    # backbone once, codebook0_head, then 31 x {projection, the 4-layer depth decoder, audio_head[i-1]}); activations / KV are negligible
+    params_frame = bb["num_layers"] * lin(bb) + D * V + (n - 1) * (D * Dd + dc["num_layers"] * lin(dc) + Dd * V)
+    bytes_frame = 2.0 * params_frame
+    audio_s = world * B * FRAMES * 0.08 * args.steps
+    out = {
+        "metric": "audio-sec/sec (xRT), CSM-1B + Mimi, batch=8 streams, reference-audio prompt, end to end",
+        "value": audio_s / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 weights, f32 arithmetic (frame generator); fp32 Mimi.encode, bf16 Mimi.decode",
+        "data": "synthetic (seeded random-init CSM-1B and Mimi weights, noise reference audio, random token ids, greedy frames, EOS ignored)",
+        "config": {"workload": f"CSM-1B (llama-1B backbone + llama-100M depth decoder) + Mimi codec: B={B} streams/GPU, prompt = {REF_S:.0f} s reference "
+                               f"audio ({S - N_TEXT} Mimi frames incl. the EOS frame) + {N_TEXT} text ids = {S} positions, {FRAMES} frames ({FRAMES * 0.08:.0f} s) "
+                               f"generated per stream, Mimi.decode included; replicas x{world}",
+                   "global_batch": B * world, "parallelism": f"replicas x{world}"},
+        "ms_per_frame": ms_frame, "frames_per_step": FRAMES,
+        "roofline": {"bound": "hbm", "kernel": "CSM frame step (five launches per Llama layer on fused_gemv_kernel; 16 + 31 x 4 layer passes)",
+                     "achieved": bytes_frame / (ms_frame * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": bytes_frame / (ms_frame * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                     "bytes_per_frame": bytes_frame, "note": "algorithmic bytes = every Linear matrix a frame multiplies by, in bf16; one launch = one frame step "
+                     "(hipGraph replay), duration from HIP events on the launch stream over 50 frames"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_csm(cfg, w, mcfg, mw, res, S)
+    return out
+
+
+def cpu_baseline_csm(cfg, w, mcfg, mw, res, S):
+    """The CPU oracles (kind "port") on a bounded sample of the same workload: ONE stream, a prompt block of the same length, 2 frames, and
+    the Mimi decode of those frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import csm_oracle as CO
+    import mimi_oracle as MO
+
+    n = cfg["audio_num_codebooks"]
+    rng = np.random.default_rng(0)
+    wb = {k: torch.tensor(np.asarray(v, np.float32)).to(torch.bfloat16).float().numpy() for k, v in w.items()}
+    orc = CO.CsmOracle(wb, cfg)
+    tok = np.zeros((1, S, n + 1), np.int64)
+    msk = np.zeros((1, S, n + 1), np.float32)
+    tok[:, :, -1] = rng.integers(0, cfg["text_vocab_size"], (1, S))
+    msk[:, :, -1] = 1
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    frames = []
+    for _ in range(2):
+        c = orc.generate_frame(tok, msk)
+        frames.append(c)
+        tok = np.zeros((1, 1, n + 1), np.int64)
+        tok[:, 0, :n] = c
+        msk = np.zeros((1, 1, n + 1), np.float32)
+        msk[:, 0, :n] = 1
+    MO.MimiOracle(mw, mcfg).decode(np.stack(frames, 2))
+    dt = time.time() - t0
+    return {"value": 2 * 0.08 / dt, "unit": "audio-sec/sec", "cores": int(cores), "kind": "port",
+            "sample": f"1 stream: prompt block of {S} positions + 2 frames (0.16 s of audio) + Mimi decode in {dt:.1f} s; oracle/csm_oracle.py + oracle/mimi_oracle.py, torch-CPU fp32"}
 
 
 def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
