@@ -113,6 +113,7 @@ SIGNATURES = {
     "kk_mimi_debug_info": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kk_mimi_debug_fetch": (_i, [_vp, _vp, C.c_char_p, _vp]),
     "kk_debug_set_op_wfrag": (None, [_vp]),
+    "kk_debug_set_op_variant": (None, [_i]),
     "kk_set_graph_mode": (_i, [_vp, _i]),
     "kk_set_quantization": (_i, [_vp, _i, _i]),
     "kk_quantized_layers": (_i, [_vp]),

@@ -35,7 +35,15 @@
 #define TR_ADD(slot, v) do { } while (0)
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
+// Two floats WITHOUT the packed-f32 instructions (v_pk_fma_f32 ...): beside another wave's MFMAs on the same SIMD the packed forms run at
+// about half rate (variant 5's service waves showed it first; here 2-6 % per fused launch).  Built with -fno-slp-vectorize for the same reason.
+struct v2f {
+  float x, y;
+};
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f& operator+=(v2f& a, v2f b) { a.x += b.x; a.y += b.y; return a; }
+__device__ __forceinline__ v2f& operator*=(v2f& a, v2f b) { a.x *= b.x; a.y *= b.y; return a; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
               for (int k = 0; k < 4; ++k) {
                 const v2f r = {__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
                 st_s[k] += r;
-                st_q[k] = __builtin_elementwise_fma(r, r, st_q[k]);
+                st_q[k] = fma2(r, r, st_q[k]);
               }
             }
           }

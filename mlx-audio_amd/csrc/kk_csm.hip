@@ -702,7 +702,6 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
     for (int i = 0; i < MP; ++i) acc[c][i] = sk2f{0.f, 0.f};
   for (int kc = k_lo; kc < k_hi; kc += KCH) {
     const int kn = min(KCH, k_hi - kc);
-    const int total = NQ * kn;
     __syncthreads();  // (the previous chunk's readers are done)
     // ---- stage the chunk: thread t takes k = t, t + 256, ... and reads that column of EVERY input row (coalesced along k), one 16-byte LDS
     // store per row quad.  All of a pass's loads are requested before anything is computed; with the norm prologue the row norms come out

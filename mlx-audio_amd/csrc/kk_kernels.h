@@ -47,6 +47,9 @@ int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a lau
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
 // variant 4 (kk_conv_mfma4.hip): W fragments straight from global memory into the MFMA operand registers; 192-row tiles, bf16 out
 int kk_launch_conv_mfma4(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
+// variant 5 (kk_conv_mfma5.hip): wave-specialised persistent kernel (4 MFMA waves + 4 service waves per CU) for stride-1 convolutions
+bool kk_mfma5_eligible(const KKMfmaArgs& a, int out_dtype);
+int kk_launch_conv_mfma5(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);
 long long kk_mfma4_pack_index(int tap, int cout, int k, int CoutP, int CinP);
 int kk_launch_pack_w_frag(const void* w, void* wf, int Kw, int CoutP, int CinP, hipStream_t st);
 // rows per statistics tile of the kernel kk_launch_conv_mfma will pick for these arguments

@@ -20,6 +20,7 @@
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static const void* g_op_wfrag = nullptr;  // kk_debug_set_op_wfrag: fragment-order weights for the single-kernel conv entry points
+static int g_op_variant = 4;              // kk_debug_set_op_variant: which fragment-order kernel they use (4 or 5)
 
 int kk_fail(const char* msg) {
   g_err = msg ? msg : "unknown error";
@@ -168,6 +169,7 @@ struct kk_model {
   bool capturing = false;
   bool no_v4 = false;
   bool no_fp8 = false;  // tests: quantised model, but the Q1 layer set runs on the bf16 kernel with the same (dequantised) weights
+  bool use_v5 = false;          // opt-in (tests / A-B): the wave-specialised persistent kernel (variant 5) where eligible; see DESIGN.md for why it is not the default
   bool no_head_fusion = false;  // tests / A-B: stand-alone conv_post + iSTFT head kernels instead of the fused head (kk_head.hip)
   bool keep_debug = false;      // tests: also materialise the tensors fused kernels skip (conv_post)
   size_t head_wf_off = 0;       // conv_post in the fused head's fragment order (bf16), 0 = not eligible
@@ -907,8 +909,10 @@ struct Ctx {
       // variant 4 (W fragments straight into registers): bf16 outputs at the default 192-row tile
       const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4;
       g.wf = v4 ? w.wf : nullptr;
+      // variant 5 (wave-specialised, persistent) takes the stride-1 convolutions; the polyphase transposed ones stay on variant 4
+      const bool v5 = v4 && m->use_v5 && B <= 256 && kk_mfma_tile_rows(Q) == 192 && kk_mfma5_eligible(g, out.dtype);
       prof_start();
-      const int rc = v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
+      const int rc = v5 ? kk_launch_conv_mfma5(g, B, out.dtype, st) : v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
       prof_stop(1, flops, bytes);
       return rc;
     }
@@ -1589,7 +1593,7 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
       (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4,
-      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug};
+      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->use_v5};
   kk_model::GraphEntry* ge = nullptr;
   for (auto& g : m->graphs)
     if (g.key == key) ge = &g;
@@ -1682,6 +1686,7 @@ extern "C" int kk_op_conv1d_bf16(void* stream, int B, const void* x, int ldx, in
   if (!kk_mfma_eligible(CinP, Cout, Kw, g.mode, stride, dil)) return kk_fail("kk_op_conv1d_bf16: shape not eligible for the MFMA kernel");
   if (g_op_wfrag && out_dtype == KK_BF16) {
     g.wf = (const bf16_t*)g_op_wfrag;
+    if (g_op_variant == 5 && kk_mfma5_eligible(g, out_dtype)) return kk_launch_conv_mfma5(g, B, out_dtype, (hipStream_t)stream);
     return kk_launch_conv_mfma4(g, B, out_dtype, (hipStream_t)stream);
   }
   return kk_launch_conv_mfma(g, B, out_dtype, (hipStream_t)stream);
@@ -1708,6 +1713,7 @@ extern "C" int kk_op_conv1d_bf16_fused(void* stream, int B, const void* x, int l
   if (!kk_mfma_eligible(CinP, Cout, Kw, KK_CONV, 1, dil)) return kk_fail("kk_op_conv1d_bf16_fused: shape not eligible for the MFMA kernel");
   if (g_op_wfrag) {
     g.wf = (const bf16_t*)g_op_wfrag;
+    if (g_op_variant == 5 && kk_mfma5_eligible(g, KK_BF16)) return kk_launch_conv_mfma5(g, B, KK_BF16, (hipStream_t)stream);
     return kk_launch_conv_mfma4(g, B, KK_BF16, (hipStream_t)stream);
   }
   return kk_launch_conv_mfma(g, B, KK_BF16, (hipStream_t)stream);
@@ -1836,6 +1842,7 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
   m->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
   m->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
+  m->use_v5 = (on & 64) != 0;          // bit 6: the wave-specialised persistent conv kernel (variant 5) where eligible, instead of variant 4
 }
 
 // load_model's quantization branch (mlx_audio/tts/utils.py:241-260): the checkpoint's Linear / Embedding weights went through MLX's
@@ -1884,6 +1891,7 @@ extern "C" int kk_op_linear_mxfp8(void* stream, const void* x_bf16, int ldx, int
   return kk_launch_linear_mxfp8(f, (hipStream_t)stream);
 }
 extern "C" void kk_debug_set_op_wfrag(const void* w_frag) { g_op_wfrag = w_frag; }
+extern "C" void kk_debug_set_op_variant(int v) { g_op_variant = v == 5 ? 5 : 4; }
 extern "C" int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP) {
   return kk_launch_pack_w_frag(w_bf16, w_frag, Kw, CoutP, CinP, (hipStream_t)stream);
 }

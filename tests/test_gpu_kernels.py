@@ -510,12 +510,14 @@ class _wfrag:
             rc = self.lib.kk_op_pack_w_frag(stream(), P(self.wd), P(self.wf), K, CoutP, CinP)
             assert rc == 0, self.lib.kk_last_error()
             self.lib.kk_debug_set_op_wfrag(P(self.wf))
+            self.lib.kk_debug_set_op_variant(5 if self.on == 5 else 4)
         return self
 
     def __exit__(self, *a):
         if self.on:
             torch.cuda.synchronize()
             self.lib.kk_debug_set_op_wfrag(None)
+            self.lib.kk_debug_set_op_variant(4)
 
 
 def run_conv_bf16(lib, x_nlc, w_oki, bias, *, transposed=False, stride=1, pad=0, dil=1, in_shift=0, in_slope=1.0, act=0, act_slope=0.0,
@@ -758,9 +760,10 @@ LONG_CASES = [
 ]
 
 
-@pytest.fixture(params=[False, True], ids=["lds_staged", "variant4"])
+@pytest.fixture(params=[False, True, 5], ids=["lds_staged", "variant4", "variant5"])
 def mfma4(request):
-    """Both bf16 MFMA kernels: the LDS-staged one and variant 4 (W fragments straight from global memory into registers)."""
+    """The three bf16 MFMA kernels: the LDS-staged one, variant 4 (W fragments straight from global memory into registers) and variant 5
+    (wave-specialised persistent: 4 MFMA waves + 4 service waves per CU; stride-1 convolutions, everything else falls through to variant 4)."""
     global _VARIANT4
     _VARIANT4 = request.param
     yield request.param

@@ -59,6 +59,7 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
         wf = torch.empty_like(w)
         assert lib.kk_op_pack_w_frag(st(), P(w), P(wf), K, CoutP, CinP) == 0
         lib.kk_debug_set_op_wfrag(P(wf))
+        lib.kk_debug_set_op_variant(5 if V5 else 4)
     call = call_fused if fused else call_plain
     call()
     torch.cuda.synchronize()
@@ -80,18 +81,29 @@ def run(name, B, L, Cin, Cout, K, dil, res, iters=5, fused=False):
         n = max(1, buf[5])
         trace = {"blocks": int(buf[5]), "prologue": buf[0] // n, "main_loop": buf[1] // n, "main.w_wait_store": buf[2] // n,
                  "main.x_barrier_transform": buf[3] // n, "epi.acc_in_lds": buf[6] // n, "epi.pass0_stored": buf[7] // n, "total_to_store_end": buf[4] // n}
+    if V5 and hasattr(lib, "kk_debug_mfma5_trace") and os.environ.get("KK_HIP_LIB"):
+        buf = (C.c_ulonglong * 8)()
+        lib.kk_debug_mfma5_trace(None, 1)
+        call()
+        torch.cuda.synchronize()
+        lib.kk_debug_mfma5_trace(buf, 1)
+        nwg = 256.0
+        trace = {"mfma.loop": buf[0] / nwg, "mfma.wait_A": buf[1] / nwg, "mfma.A_to_B": buf[2] / nwg, "svc.loop": buf[3] / nwg, "svc.wait_A": buf[4] / nwg,
+                 "svc.A_to_B": buf[5] / nwg, "svc.epilogue": buf[6] / nwg, "svc.load_transform": buf[7] / nwg}
+        trace = {k: int(v) for k, v in trace.items()}
     fl = 2.0 * B * L * Cin * Cout * K
     by = B * L * (Cin + Cout * (2 if res else 1)) * 2
     if V4:
         torch.cuda.synchronize()
         lib.kk_debug_set_op_wfrag(None)
-    out = {"name": name + ("+fused" if fused else "") + ("+v4" if V4 else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
+    out = {"name": name + ("+fused" if fused else "") + ("+v5" if V5 else "+v4" if V4 else ""), "ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "GBs": round(by / ms / 1e6, 1)}
     if trace:
         out["trace_cycles"] = trace
     return out
 
 
-V4 = "--v4" in sys.argv
+V5 = "--v5" in sys.argv
+V4 = "--v4" in sys.argv or V5
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
