@@ -236,20 +236,24 @@ int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int32_t* codes
 int kk_mimi_encode_frames(const kk_mimi* m, int N); /* ceil chain over the ratios and the resampler: 120000 -> 63 */
 size_t kk_mimi_encode_workspace_bytes(kk_mimi* m, int B, int N);
 int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out);
-/* Streaming decode: Mimi.decode_step / MimiStreamingDecoder (mimi.py:163-168,264-306; conv.py:265-351; seanet.py:219-223,277-283).
- * A stream owns its state in device memory: the previous quantised frame (the 2x resampler looks back one frame), the KV caches of the
- * decoder transformer (last 250 cached positions + the step's own, no mask: transformer.py:79-104) and a window of the last 16 transformer
- * outputs over which the causal SEANet decoder is re-run each step (it equals the reference's per-layer conv state exactly: a causal
- * convolution's streaming output is its offline output at those positions).  codes [B][nq] int32 (one frame) -> pcm [B][samples_per_frame].
- * fp32 kernels; B is fixed between resets; at most max_frames steps per reset. */
+/* Streaming: Mimi.decode_step / Mimi.encode_step / MimiStreamingDecoder (mimi.py:156-168,264-306; conv.py:265-351; seanet.py:219-223,277-283).
+ * A stream owns the state the reference's streaming modules own, in device memory: per causal convolution the last k - stride input rows
+ * (StreamableConv1d._prev_xs), per transposed convolution (k = 2 stride) the previous input row -- one row that determines the stride rows
+ * of partial sums StreamableConvTranspose1d._prev_ys keeps --, the resampler's previous frame, and the KV caches of the transformer (last
+ * 250 cached positions + the step's own, no mask: transformer.py:79-104).  Each step runs every layer over the rows of `chunk_frames` code
+ * frames only.  decode: codes [B][nq][chunk] int32 -> pcm [B][chunk * samples_per_frame]; encode: the reverse.  fp32 kernels; B is fixed
+ * between resets; at most max_frames frames per reset; a stream is created for one direction. */
 typedef struct kk_mimi_stream kk_mimi_stream;
-int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out);
+int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out); /* decode, one frame per step */
+int kk_mimi_stream_create_chunked(kk_mimi* m, int encoder, int max_batch, int max_frames, int chunk_frames, kk_mimi_stream** out);
 void kk_mimi_stream_destroy(kk_mimi_stream* s);
-int kk_mimi_stream_reset(kk_mimi_stream* s); /* MimiStreamingDecoder.reset */
+int kk_mimi_stream_reset(kk_mimi_stream* s); /* MimiStreamingDecoder.reset / Mimi.reset_state (mimi.py:131-137) */
 int kk_mimi_stream_frames(const kk_mimi_stream* s);
+int kk_mimi_stream_chunk_frames(const kk_mimi_stream* s);
 int kk_mimi_stream_set_context(kk_mimi_stream* s, int context); /* TransformerConfig.context, default 250 (mimi.py:55-77); fresh / reset stream only */
 size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B);
 int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);
+int kk_mimi_encode_step(kk_mimi_stream* s, void* stream, int B, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out); /* Mimi.encode_step (mimi.py:156-161) */
 /* intermediates of the last decode / encode (tests): "quantized", "upsampled", "transformer", "layer0".."layer3" (decode), "seanet", "transformer", "downsampled" (encode); [B][rows][channels] fp32 */
 int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels);
 int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst);

@@ -101,6 +101,9 @@ SIGNATURES = {
     "kk_mimi_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kk_mimi_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_stream_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "kk_mimi_stream_create_chunked": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "kk_mimi_stream_chunk_frames": (_i, [_vp]),
+    "kk_mimi_encode_step": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_stream_destroy": (None, [_vp]),
     "kk_mimi_stream_reset": (_i, [_vp]),
     "kk_mimi_stream_frames": (_i, [_vp]),

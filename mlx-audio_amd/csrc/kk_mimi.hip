@@ -370,7 +370,8 @@ void resolve(kk_mimi* m, PackedVec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 struct Act {  // an activation tensor [B][rows][ld], C valid channels
   void* p = nullptr;
   int rows = 0, C = 0, ld = 0, dtype = KK_F32;
-  long long bs() const { return (long long)rows * ld; }
+  long long bstride = 0;  // 0: dense (rows * ld); set for a row range of a larger per-item buffer
+  long long bs() const { return bstride ? bstride : (long long)rows * ld; }
 };
 
 struct Run {
@@ -559,29 +560,66 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------- streaming decode
-// Mimi.decode_step (mimi.py:163-168) / MimiStreamingDecoder (mimi.py:264-306).  Every convolution of the decode path is causal, so what
-// the reference's per-module state (StreamableConv1d._prev_xs, StreamableConvTranspose1d._prev_ys, conv.py:265-351) computes for a new
-// frame is exactly the offline causal convolution at those positions; it depends on a bounded look-back (init conv: 6 frames of the
-// 25 Hz stream, each decoder layer one more input sample).  So the stream keeps NO per-layer conv state: it keeps the previous quantised
-// frame (the 2x resampler looks back one), the KV caches of the transformer -- the one stateful module whose streaming result differs
-// from decode(): it sees the past only, the last `context` cached positions, and the positions of one step see each other
-// (no mask, transformer.py:79-104) -- and a WINDOW of the last SW transformer outputs, over which the offline SEANet kernels run each
-// step; the last frame's samples of that run are the step's output (window >= look-back + new rows, checked at create).
-constexpr int MIMI_SW = 16;  // transformer-output rows kept (25 Hz rows: 8 code frames)
-
-int seanet_lookback_rows(const kk_mimi_config& c) {
-  // rows of the 25 Hz stream an output sample can depend on, beyond its own: init conv k-1, then per layer one input sample of the
-  // transposed conv + (residual_ksize - 1) samples at the layer's rate -- converted to 25 Hz rows (rounded up)
-  double look = c.ksize - 1;
-  double rate = 1.0;  // samples per 25 Hz row at the input of the layer
-  for (int l = 0; l < c.n_ratios; ++l) {
-    look += 1.0 / rate;
-    rate *= c.ratios[l];
-    look += (double)(c.residual_ksize - 1) / rate;
+// ------------------------------------------------------------------------------------------------------------- streaming
+// Mimi.decode_step / encode_step (mimi.py:156-168), MimiStreamingDecoder (mimi.py:264-306).  Every module carries the state the
+// reference's streaming modules carry (conv.py:265-351):
+//   * StreamableConv1d._prev_xs: the last (k - 1) * dilation + 1 - stride INPUT rows of each causal convolution.  Here a StateBuf per
+//     convolution, [item][S carried rows | n rows of this step]: the producer writes its rows straight behind the carried ones, the
+//     convolution runs without padding over S + n rows, then the last S rows move to the front.  A fresh stream holds zeros there
+//     (the left padding of the first step; 'edge' for the resampler, filled from the first row).
+//   * StreamableConvTranspose1d._prev_ys (k = 2 * stride): the partial sums of the last stride output rows.  An output row depends on two
+//     input rows, so carrying the previous INPUT row (one row instead of stride rows of partial sums) and running the transposed
+//     convolution over [previous | new] rows gives the same sums; the first `stride` rows of that run repeat the previous step's and are
+//     dropped.  ELU(0) = 0 and no bias on a zero row: a zero row stands for "no previous input".
+//   * the transformers' KV caches (positions of one step see each other and the last `context` cached ones, transformer.py:79-104).
+// Chunks are whole code frames, so every layer sees a fixed number of rows per step and no module ever has to hold back a partial stride.
+struct StateBuf {
+  float* p = nullptr;
+  int S = 0, n = 0, C = 0, maxB = 0;
+  size_t floats() const { return (size_t)maxB * (S + n) * C; }
+  Act all() const {
+    Act t;
+    t.p = p; t.rows = S + n; t.C = C; t.ld = C; t.dtype = KK_F32;
+    return t;
   }
-  look += (double)(c.last_ksize - 1) / rate;
-  return (int)ceil(look);
+  Act fresh() const {
+    Act t;
+    t.p = p + (size_t)S * C; t.rows = n; t.C = C; t.ld = C; t.dtype = KK_F32;
+    t.bstride = (long long)(S + n) * C;
+    return t;
+  }
+};
+
+// rows [n, n + S) -> rows [0, S) of every item; the ranges overlap when n < S, so a block reads everything before it writes
+constexpr int SHIFT_PER_THREAD = 32;
+__global__ __launch_bounds__(256) void state_shift_kernel(float* p, int S, int n, int C) {
+  float* q = p + (long long)blockIdx.x * (S + n) * C;
+  const int total = S * C;
+  float v[SHIFT_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < SHIFT_PER_THREAD; ++k) {
+    const int e = threadIdx.x + k * 256;
+    v[k] = e < total ? q[(long long)n * C + e] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SHIFT_PER_THREAD; ++k) {
+    const int e = threadIdx.x + k * 256;
+    if (e < total) q[e] = v[k];
+  }
+}
+// 'edge' left padding of a fresh resampler state (conv.py:265-281 with pad_mode "edge"): the carried rows repeat the first new row
+__global__ __launch_bounds__(256) void state_edge_fill_kernel(float* p, int S, int n, int C) {
+  float* q = p + (long long)blockIdx.x * (S + n) * C;
+  for (int e = threadIdx.x; e < S * C; e += 256) q[e] = q[(long long)S * C + e % C];
+}
+
+int state_shift(const StateBuf& b, int B, hipStream_t st) {
+  if (b.S == 0) return 0;
+  if (b.S * b.C > 256 * SHIFT_PER_THREAD) return kk_fail("mimi stream: carried state larger than the shift kernel takes");
+  hipLaunchKernelGGL(state_shift_kernel, dim3(B), dim3(256), 0, st, b.p, b.S, b.n, b.C);
+  KK_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // namespace
@@ -589,86 +627,220 @@ int seanet_lookback_rows(const kk_mimi_config& c) {
 struct kk_mimi_stream {
   kk_mimi* m = nullptr;
   int max_batch = 0, max_pos = 0, context = 250;
-  float* xprev = nullptr;  // [maxB][dim]       previous quantised frame
-  float* tw = nullptr;     // [maxB][SW][dim]   last transformer outputs
+  bool encoder = false;
+  int chunk = 1;           // code frames per step
   float* kc = nullptr;     // [layers][maxB][max_pos][dim]
   float* vc = nullptr;
   float* rope = nullptr;   // [max_pos][hd/2][2]
-  int frames = 0, tw_rows = 0, pos = 0, B = 0;
+  float* pool = nullptr;   // every StateBuf below
+  size_t pool_floats = 0;
+  // decode: resampler (previous quantised frame), init conv, per layer [transposed conv | residual block], last conv
+  // encode: init conv, per layer [residual block | strided conv], last conv, resampler
+  StateBuf first, last, resample;
+  std::vector<StateBuf> up, blk;
+  int frames = 0, pos = 0, B = 0;
+  bool fresh = true;
 };
 
 namespace {
 
-int run_decode_step(Run& r, kk_mimi_stream* s, const int* codes, float* pcm_out) {
-  kk_mimi* m = r.m;
-  const kk_mimi_config& c = m->cfg;
-  const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, H = c.num_heads, hd = D / H;
-  const int win = s->frames > 0 ? 2 : 1;  // quantised frames the resampler sees: [previous, current]
-  const KKLen one{nullptr, 0, 1};
-  Act q1 = r.act(1, Q), q2 = r.act(1, Q), xc = r.act(1, D), xw = r.act(win, D), xu = r.act(win * us, D), x = r.act(us, D), xup = r.act(us, D);
-  Act n = r.act(us, D), qkv = r.act(us, 3 * D), att = r.act(us, D), hbuf = r.act(us, c.dim_feedforward);
-  const int Lw = std::min(MIMI_SW, s->tw_rows + us);  // rows the SEANet run covers after this step's rows are appended
-  Act xa = r.act(Lw, D);
-  long long spr = 1;
-  for (int l = 0; l < c.n_ratios; ++l) spr *= c.ratios[l];
-  float* pcm_w = (float*)r.raw((size_t)B * Lw * spr * 4);
-  float* shift = (float*)r.raw((size_t)B * MIMI_SW * D * 4);
-  if (r.oom) return kk_fail("kk_mimi_decode_step: workspace too small");
-  if (r.dry) {  // sizes only: the SEANet scratch of a full window
-    Act full = r.act(MIMI_SW, D);
-    (void)r.raw((size_t)B * MIMI_SW * spr * 4);
-    return run_seanet(r, full, nullptr, "kk_mimi_decode_step");
-  }
-  if (s->pos + us > s->max_pos) return kk_fail("kk_mimi_decode_step: the stream is longer than max_frames (kk_mimi_stream_create)");
-  // ---- quantizer.decode of the one new frame
-  hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(1, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, 1, q1.ld, (float*)q1.p, (float*)q2.p);
-  KK_CHECK_LAUNCH();
-  MM_TRY(r.conv(m->proj_first, q1, xc, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
-  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, xc, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
-  // ---- upsample.step: the resampler over [previous, current], its last `us` rows are the new ones
-  if (win == 2) MM_TRY(kk_launch_copy_slice(s->xprev, D, D, xw.p, xw.bs(), D, 0, D, 1, one, B, KK_F32, r.st));
-  MM_TRY(kk_launch_copy_slice(xc.p, xc.bs(), D, (float*)xw.p + (size_t)(win - 1) * D, xw.bs(), D, 0, D, 1, one, B, KK_F32, r.st));
-  MM_TRY(kk_launch_copy_slice(xc.p, xc.bs(), D, s->xprev, D, D, 0, D, 1, one, B, KK_F32, r.st));
-  hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(win * us, B), dim3(256), 0, r.st, (const float*)xw.p, m->up_w.p, D, xw.ld, win, us, (float*)xu.p);
-  KK_CHECK_LAUNCH();
-  const KKLen lus{nullptr, 0, us};
-  MM_TRY(kk_launch_copy_slice((float*)xu.p + (size_t)(win - 1) * us * D, xu.bs(), D, x.p, x.bs(), D, 0, D, us, lus, B, KK_F32, r.st));
-  MM_TRY(kk_launch_copy_slice(x.p, x.bs(), D, xup.p, xup.bs(), D, 0, D, us, lus, B, KK_F32, r.st));  // debug hook: the transformer updates x in place
-  r.note("upsampled", xup);
-  // ---- decoder_transformer with the KV caches (transformer.py:79-104,137-177)
-  for (size_t l = 0; l < m->layers.size(); ++l) {
-    const MimiLayer& L = m->layers[l];
+// one step of a transformer stack over the stream's KV caches: x [B][T rows][D] in place (transformer.py:79-104,137-177)
+int run_transformer_step(Run& r, kk_mimi_stream* s, const std::vector<MimiLayer>& layers, Act& x, Act& n, Act& qkv, Act& att, Act& hbuf) {
+  const kk_mimi_config& c = r.m->cfg;
+  const int B = r.B, D = c.dim, H = c.num_heads, hd = D / H, T = x.rows;
+  for (size_t l = 0; l < layers.size(); ++l) {
+    const MimiLayer& L = layers[l];
     float* kcl = s->kc + (size_t)l * s->max_batch * s->max_pos * D;
     float* vcl = s->vc + (size_t)l * s->max_batch * s->max_pos * D;
     MM_TRY(r.layernorm(x, n, L.n1w.p, L.n1b.p));
     MM_TRY(r.conv(L.in_proj, n, qkv, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
-    MM_TRY(kk_launch_rope_append((float*)qkv.p, us, H, H, hd, s->rope, s->pos, kcl, vcl, s->max_pos, B, r.st));
-    MM_TRY(kk_launch_attn_cache((const float*)qkv.p, us, H, H, hd, s->pos, kcl, vcl, s->max_pos, 1.0f / sqrtf((float)hd), (float*)att.p, 0, s->context, B, r.st));
+    if (!r.dry) {
+      MM_TRY(kk_launch_rope_append((float*)qkv.p, T, H, H, hd, s->rope, s->pos, kcl, vcl, s->max_pos, B, r.st));
+      MM_TRY(kk_launch_attn_cache((const float*)qkv.p, T, H, H, hd, s->pos, kcl, vcl, s->max_pos, 1.0f / sqrtf((float)hd), (float*)att.p, 0, s->context, B, r.st));
+    }
     MM_TRY(r.conv(L.out_proj, att, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));
     MM_TRY(r.layernorm(x, n, L.n2w.p, L.n2b.p));
     MM_TRY(r.conv(L.lin1, n, hbuf, 0, 1, false, 1, 0, KK_ACT_GELU_TANH, nullptr, 0));
     MM_TRY(r.conv(L.lin2, hbuf, x, 0, 1, false, 1, 0, KK_ACT_NONE, &x, 0));
   }
-  r.note("transformer", x);
-  // ---- window of transformer outputs: drop the oldest rows when full, append the new ones
-  const long long twbs = (long long)MIMI_SW * D;
-  if (s->tw_rows + us > MIMI_SW) {
-    const int keep = MIMI_SW - us;
-    const KKLen lk{nullptr, 0, keep};
-    MM_TRY(kk_launch_copy_slice(s->tw + (size_t)(s->tw_rows - keep) * D, twbs, D, shift, twbs, D, 0, D, keep, lk, B, KK_F32, r.st));
-    MM_TRY(kk_launch_copy_slice(shift, twbs, D, s->tw, twbs, D, 0, D, keep, lk, B, KK_F32, r.st));
-    s->tw_rows = keep;
+  return 0;
+}
+
+int copy_rows(Run& r, const Act& src, int src_row0, const Act& dst, int rows) {
+  if (r.dry) return 0;
+  const KKLen len{nullptr, 0, rows};
+  return kk_launch_copy_slice((const float*)src.p + (size_t)src_row0 * src.ld, src.bs(), src.ld, dst.p, dst.bs(), dst.ld, 0, dst.C, rows, len, r.B, KK_F32, r.st);
+}
+
+// lays the stream's state buffers out (sizes only when pool == nullptr); returns the floats needed
+size_t stream_layout(kk_mimi_stream* s, float* pool) {
+  const kk_mimi* m = s->m;
+  const kk_mimi_config& c = m->cfg;
+  const int us = c.upsample_stride, D = c.dim, mb = s->max_batch;
+  size_t off = 0;
+  auto place = [&](StateBuf& b, int S, int n, int C) {
+    b.S = S; b.n = n; b.C = C; b.maxB = mb;
+    b.p = pool ? pool + off : nullptr;
+    off += (b.floats() + 63) & ~(size_t)63;
+  };
+  const int F = s->chunk;
+  s->up.assign(c.n_ratios, StateBuf());
+  s->blk.assign(c.n_ratios, StateBuf());
+  if (!s->encoder) {
+    place(s->resample, 1, F, D);                       // quantised frames: [previous | new]
+    int rows = F * us;
+    place(s->first, c.ksize - 1, rows, D);
+    for (int l = 0; l < c.n_ratios; ++l) {
+      const SeaLayer& L = m->sea[l];
+      place(s->up[l], 1, rows, L.up.Cin);            // [previous input row | new rows] of the transposed conv
+      rows *= L.ratio;
+      place(s->blk[l], c.residual_ksize - 1, rows, L.up.Cout);
+    }
+    place(s->last, c.last_ksize - 1, rows, m->final_conv.Cin);
+  } else {
+    long long rows = (long long)F * kk_mimi_samples_per_frame(m);
+    place(s->first, c.ksize - 1, (int)rows, 1);
+    for (int l = 0; l < c.n_ratios; ++l) {
+      const SeaLayer& L = m->enc_sea[l];
+      place(s->blk[l], c.residual_ksize - 1, (int)rows, L.b0.Cin);
+      place(s->up[l], L.up.K - L.ratio, (int)rows, L.up.Cin);  // the strided conv carries k - stride rows
+      rows /= L.ratio;
+    }
+    place(s->last, c.last_ksize - 1, (int)rows, m->enc_final.Cin);
+    place(s->resample, us, (int)rows, D);              // conv k = 2 us, stride us: carries us rows
   }
-  MM_TRY(kk_launch_copy_slice(x.p, x.bs(), D, s->tw + (size_t)s->tw_rows * D, twbs, D, 0, D, us, lus, B, KK_F32, r.st));
-  s->tw_rows += us;
-  // ---- decoder.step: the offline SEANet over the window; the step's samples are the last us * spr of the run
-  const KKLen lw{nullptr, 0, Lw};
-  MM_TRY(kk_launch_copy_slice(s->tw, twbs, D, xa.p, xa.bs(), D, 0, D, Lw, lw, B, KK_F32, r.st));
-  MM_TRY(run_seanet(r, xa, pcm_w, "kk_mimi_decode_step"));
-  const int nout = (int)(us * spr);
-  MM_TRY(kk_launch_copy_slice(pcm_w + (size_t)Lw * spr - nout, (long long)Lw * spr, nout, pcm_out, nout, nout, 0, nout, 1, one, B, KK_F32, r.st));
-  s->pos += us;
-  s->frames += 1;
+  return off;
+}
+
+int stream_begin(Run& r, kk_mimi_stream* s) {  // zero state on the first step after create / reset
+  if (r.dry || !s->fresh) return 0;
+  if (hipMemsetAsync(s->pool, 0, s->pool_floats * 4, r.st) != hipSuccess) return kk_fail("mimi stream: state reset failed");
+  return 0;
+}
+
+int run_decode_step(Run& r, kk_mimi_stream* s, const int* codes, float* pcm_out) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, F = s->chunk;
+  Act q1 = r.act(F, Q), q2 = r.act(F, Q), xu = r.act((F + 1) * us, D), x = r.act(F * us, D), xup = r.act(F * us, D);
+  Act n = r.act(F * us, D), qkv = r.act(F * us, 3 * D), att = r.act(F * us, D), hbuf = r.act(F * us, c.dim_feedforward);
+  if (r.oom) return kk_fail("kk_mimi_decode_step: workspace too small");
+  if (!r.dry && s->pos + F * us > s->max_pos) return kk_fail("kk_mimi_decode_step: the stream is longer than max_frames (kk_mimi_stream_create)");
+  MM_TRY(stream_begin(r, s));
+  // ---- quantizer.decode of the new frames, straight behind the previous one
+  Act xq = s->resample.fresh();
+  if (!r.dry) {
+    hipLaunchKernelGGL(rvq_sum_kernel<float>, dim3(F, B), dim3(256), 0, r.st, codes, m->codebooks.p, c.nq, c.bins, Q, F, q1.ld, (float*)q1.p, (float*)q2.p);
+    KK_CHECK_LAUNCH();
+  }
+  MM_TRY(r.conv(m->proj_first, q1, xq, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (c.nq > 1) MM_TRY(r.conv(m->proj_rest, q2, xq, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 1));
+  // ---- upsample.step: the depthwise transposed conv over [previous | new]; its first `us` rows repeat the last step's
+  if (!r.dry) {
+    const Act w = s->resample.all();
+    hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3((F + 1) * us, B), dim3(256), 0, r.st, (const float*)w.p, m->up_w.p, D, w.ld, F + 1, us, (float*)xu.p);
+    KK_CHECK_LAUNCH();
+  }
+  MM_TRY(copy_rows(r, xu, us, x, F * us));
+  MM_TRY(copy_rows(r, x, 0, xup, F * us));  // debug hook: the transformer updates x in place
+  if (!r.dry) MM_TRY(state_shift(s->resample, B, r.st));
+  r.note("upsampled", xup);
+  // ---- decoder_transformer with the KV caches
+  MM_TRY(run_transformer_step(r, s, m->layers, x, n, qkv, att, hbuf));
+  r.note("transformer", x);
+  // ---- decoder.step (seanet.py:228-283 through each module's step)
+  MM_TRY(copy_rows(r, x, 0, s->first.fresh(), F * us));
+  MM_TRY(r.conv(m->init_conv, s->first.all(), s->up[0].fresh(), 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (!r.dry) MM_TRY(state_shift(s->first, B, r.st));
+  static const char* lname[8] = {"layer0", "layer1", "layer2", "layer3", "layer4", "layer5", "layer6", "layer7"};
+  for (size_t l = 0; l < m->sea.size(); ++l) {
+    const SeaLayer& S = m->sea[l];
+    const StateBuf& U = s->up[l];
+    const StateBuf& Bk = s->blk[l];
+    const StateBuf& nextb = l + 1 < m->sea.size() ? s->up[l + 1] : s->last;
+    Act full = r.act((U.n + 1) * S.ratio, S.up.Cout), hb = r.act(Bk.n, S.b0.Cout);
+    if (r.oom) return kk_fail("kk_mimi_decode_step: workspace too small");
+    MM_TRY(r.conv(S.up, U.all(), full, 0, 1, true, S.ratio, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(copy_rows(r, full, S.ratio, Bk.fresh(), Bk.n));
+    if (!r.dry) MM_TRY(state_shift(U, B, r.st));
+    MM_TRY(r.conv(S.b0, Bk.all(), hb, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    const Act skip = Bk.fresh();
+    MM_TRY(r.conv(S.b1, hb, nextb.fresh(), 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, &skip, 0));
+    if (!r.dry) MM_TRY(state_shift(Bk, B, r.st));
+    r.note(l < 8 ? lname[l] : "layerN", nextb.fresh());
+  }
+  Act out;
+  out.p = pcm_out; out.rows = s->last.n; out.C = 1; out.ld = 1; out.dtype = KK_F32;
+  MM_TRY(r.conv(m->final_conv, s->last.all(), out, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  if (!r.dry) {
+    MM_TRY(state_shift(s->last, B, r.st));
+    s->pos += F * us;
+    s->frames += F;
+    s->fresh = false;
+  }
+  return 0;
+}
+
+// Mimi.encode_step (mimi.py:156-161): pcm [B][chunk * samples_per_frame] -> codes [B][nq][chunk]
+int run_encode_step(Run& r, kk_mimi_stream* s, const float* pcm, int* codes) {
+  kk_mimi* m = r.m;
+  const kk_mimi_config& c = m->cfg;
+  const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, F = s->chunk, T = F * us;
+  const int N = s->first.n;
+  if (!r.dry && s->pos + T > s->max_pos) return kk_fail("kk_mimi_encode_step: the stream is longer than max_frames (kk_mimi_encode_stream_create)");
+  MM_TRY(stream_begin(r, s));
+  Act in;
+  in.p = const_cast<float*>(pcm); in.rows = N; in.C = 1; in.ld = 1; in.dtype = KK_F32;
+  MM_TRY(copy_rows(r, in, 0, s->first.fresh(), N));
+  MM_TRY(r.conv(m->enc_init, s->first.all(), s->blk[0].fresh(), 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+  if (!r.dry) MM_TRY(state_shift(s->first, B, r.st));
+  for (size_t l = 0; l < m->enc_sea.size(); ++l) {
+    const SeaLayer& S = m->enc_sea[l];
+    const StateBuf& Bk = s->blk[l];
+    const StateBuf& Dn = s->up[l];
+    const StateBuf& nextb = l + 1 < m->enc_sea.size() ? s->blk[l + 1] : s->last;
+    Act hb = r.act(Bk.n, S.b0.Cout);
+    if (r.oom) return kk_fail("kk_mimi_encode_step: workspace too small");
+    MM_TRY(r.conv(S.b0, Bk.all(), hb, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    const Act skip = Bk.fresh();
+    MM_TRY(r.conv(S.b1, hb, Dn.fresh(), 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, &skip, 0));
+    if (!r.dry) MM_TRY(state_shift(Bk, B, r.st));
+    MM_TRY(r.conv(S.up, Dn.all(), nextb.fresh(), 0, 1, false, S.ratio, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+    if (!r.dry) MM_TRY(state_shift(Dn, B, r.st));
+  }
+  Act x = r.act(T, D), n = r.act(T, D), qkv = r.act(T, 3 * D), att = r.act(T, D), hbuf = r.act(T, c.dim_feedforward);
+  Act xd = r.act(F, D), res = r.act(F, Q), dots = r.act(F, c.bins), xs = r.act(T, D);
+  if (r.oom) return kk_fail("kk_mimi_encode_step: workspace too small");
+  MM_TRY(r.conv(m->enc_final, s->last.all(), xs, 0, 1, false, 1, KK_ACT_ELU, KK_ACT_NONE, nullptr, 0));
+  if (!r.dry) MM_TRY(state_shift(s->last, B, r.st));
+  r.note("seanet", xs);
+  MM_TRY(copy_rows(r, xs, 0, x, T));  // (the transformer updates x in place; xs stays for the debug hook)
+  MM_TRY(run_transformer_step(r, s, m->enc_layers, x, n, qkv, att, hbuf));
+  r.note("transformer", x);
+  // downsample.step: conv k = 2 us, stride us, 'edge' left padding on the first step
+  MM_TRY(copy_rows(r, x, 0, s->resample.fresh(), T));
+  if (!r.dry && s->fresh) {
+    hipLaunchKernelGGL(state_edge_fill_kernel, dim3(B), dim3(256), 0, r.st, s->resample.p, s->resample.S, s->resample.n, s->resample.C);
+    KK_CHECK_LAUNCH();
+  }
+  MM_TRY(r.conv(m->enc_down, s->resample.all(), xd, 0, 1, false, us, 0, KK_ACT_NONE, nullptr, 0));
+  if (!r.dry) MM_TRY(state_shift(s->resample, B, r.st));
+  r.note("downsampled", xd);
+  for (int i = 0; i < c.nq; ++i) {  // split RVQ search, as in run_encode
+    if (i == 0) MM_TRY(r.conv(m->inproj_first, xd, res, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    if (i == 1) MM_TRY(r.conv(m->inproj_rest, xd, res, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    MM_TRY(r.conv(m->cb_dot[i], res, dots, 0, 1, false, 1, 0, KK_ACT_NONE, nullptr, 0));
+    if (!r.dry) {
+      hipLaunchKernelGGL(rvq_argmin_kernel, dim3(F, B), dim3(256), 0, r.st, (const float*)dots.p, m->c2.p + (size_t)i * c.bins,
+                         m->codebooks.p + (size_t)i * c.bins * Q, c.bins, Q, F, c.nq, i, (float*)res.p, codes);
+      KK_CHECK_LAUNCH();
+    }
+  }
+  if (!r.dry) {
+    s->pos += T;
+    s->frames += F;
+    s->fresh = false;
+  }
   return 0;
 }
 
@@ -933,17 +1105,25 @@ extern "C" int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int
   return run_decode(r, Nf, codes, pcm_out);
 }
 
-// ---- streaming decode (Mimi.decode_step / MimiStreamingDecoder, mimi.py:163-168,264-306)
-extern "C" int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out) {
-  if (!m || !m->finalized || !out || max_batch < 1 || max_frames < 1) return kk_fail("kk_mimi_stream_create: bad argument");
+// ---- streaming (Mimi.decode_step / encode_step / MimiStreamingDecoder, mimi.py:156-168,264-306)
+static int kk_fail(const char* who, const char* what) {
+  std::string msg = std::string(who) + what;
+  return kk_fail(msg.c_str());
+}
+static int stream_create(kk_mimi* m, bool encoder, int max_batch, int max_frames, int chunk_frames, kk_mimi_stream** out, const char* who) {
+  if (!m || !m->finalized || !out || max_batch < 1 || max_frames < 1 || chunk_frames < 1 || chunk_frames > max_frames) return kk_fail(who, ": bad argument");
+  if (encoder && !m->has_encoder) return kk_fail(who, ": the checkpoint held no encoder.* parameters");
   const kk_mimi_config& c = m->cfg;
   const int hd = c.dim / c.num_heads;
-  if (hd != 64 && hd != 128) return kk_fail("kk_mimi_stream_create: head size must be 64 or 128");
-  if (seanet_lookback_rows(c) + c.upsample_stride > MIMI_SW) return kk_fail("kk_mimi_stream_create: the SEANet look-back exceeds the output window");
+  if (hd != 64 && hd != 128) return kk_fail(who, ": head size must be 64 or 128");
+  for (int l = 0; l < c.n_ratios; ++l) {
+    const SeaLayer& L = encoder ? m->enc_sea[l] : m->sea[l];
+    if (L.up.K != 2 * L.ratio) return kk_fail(who, ": (transposed) conv kernel must be twice its stride");
+  }
   kk_mimi_stream* s = new (std::nothrow) kk_mimi_stream();
-  if (!s) return kk_fail("kk_mimi_stream_create: out of memory");
-  s->m = m; s->max_batch = max_batch; s->max_pos = max_frames * c.upsample_stride;
-  const size_t D = c.dim, kvn = (size_t)c.num_layers * max_batch * s->max_pos * D * 4;
+  if (!s) return kk_fail(who, ": out of memory");
+  s->m = m; s->max_batch = max_batch; s->max_pos = max_frames * c.upsample_stride; s->encoder = encoder; s->chunk = chunk_frames;
+  const size_t D = c.dim, nl = encoder ? m->enc_layers.size() : m->layers.size(), kvn = nl * max_batch * s->max_pos * D * 4;
   std::vector<float> tab((size_t)s->max_pos * (hd / 2) * 2);
   for (int p = 0; p < s->max_pos; ++p)
     for (int i = 0; i < hd / 2; ++i) {
@@ -951,28 +1131,39 @@ extern "C" int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, 
       tab[((size_t)p * (hd / 2) + i) * 2] = cosf(ang);
       tab[((size_t)p * (hd / 2) + i) * 2 + 1] = sinf(ang);
     }
-  if (hipMalloc((void**)&s->xprev, (size_t)max_batch * D * 4) != hipSuccess || hipMalloc((void**)&s->tw, (size_t)max_batch * MIMI_SW * D * 4) != hipSuccess ||
-      hipMalloc((void**)&s->kc, kvn) != hipSuccess || hipMalloc((void**)&s->vc, kvn) != hipSuccess || hipMalloc((void**)&s->rope, tab.size() * 4) != hipSuccess ||
+  s->pool_floats = stream_layout(s, nullptr);
+  if (hipMalloc((void**)&s->pool, s->pool_floats * 4) != hipSuccess || hipMalloc((void**)&s->kc, kvn ? kvn : 4) != hipSuccess ||
+      hipMalloc((void**)&s->vc, kvn ? kvn : 4) != hipSuccess || hipMalloc((void**)&s->rope, tab.size() * 4) != hipSuccess ||
       hipMemcpy(s->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
     kk_mimi_stream_destroy(s);
-    return kk_fail("kk_mimi_stream_create: hipMalloc failed");
+    return kk_fail(who, ": hipMalloc failed");
   }
+  (void)stream_layout(s, s->pool);
   *out = s;
   return 0;
 }
+extern "C" int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out) {
+  return stream_create(m, false, max_batch, max_frames, 1, out, "kk_mimi_stream_create");
+}
+// chunk_frames code frames per kk_mimi_decode_step / kk_mimi_encode_step call (fixed for the stream's life)
+extern "C" int kk_mimi_stream_create_chunked(kk_mimi* m, int encoder, int max_batch, int max_frames, int chunk_frames, kk_mimi_stream** out) {
+  return stream_create(m, encoder != 0, max_batch, max_frames, chunk_frames, out, "kk_mimi_stream_create_chunked");
+}
 extern "C" void kk_mimi_stream_destroy(kk_mimi_stream* s) {
   if (!s) return;
-  for (float* p : {s->xprev, s->tw, s->kc, s->vc, s->rope})
+  for (float* p : {s->pool, s->kc, s->vc, s->rope})
     if (p) (void)hipFree(p);
   delete s;
 }
-extern "C" int kk_mimi_stream_reset(kk_mimi_stream* s) {  // MimiStreamingDecoder.reset (mimi.py:274-279)
+extern "C" int kk_mimi_stream_reset(kk_mimi_stream* s) {  // MimiStreamingDecoder.reset / Mimi.reset_state (mimi.py:131-137,274-279)
   if (!s) return kk_fail("kk_mimi_stream_reset: null stream");
-  s->frames = s->tw_rows = s->pos = 0;
+  s->frames = s->pos = 0;
   s->B = 0;
+  s->fresh = true;  // the state buffers are zeroed on the next step's stream
   return 0;
 }
 extern "C" int kk_mimi_stream_frames(const kk_mimi_stream* s) { return s ? s->frames : -1; }
+extern "C" int kk_mimi_stream_chunk_frames(const kk_mimi_stream* s) { return s ? s->chunk : -1; }
 // TransformerConfig.context (mimi.py:55-77: 250 for mimi_202407): cached positions a step may look back on.  Only between resets.
 extern "C" int kk_mimi_stream_set_context(kk_mimi_stream* s, int context) {
   if (!s || context < 0) return kk_fail("kk_mimi_stream_set_context: bad argument");
@@ -984,23 +1175,34 @@ extern "C" size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B) {
   if (!s || B < 1 || B > s->max_batch) return 0;
   Run r{s->m, nullptr, B, nullptr, 0, 0, true, false};
   r.adt = KK_F32;
-  kk_mimi_stream probe = *s;
-  probe.frames = 1;  // the two-frame resampler window
-  probe.tw_rows = MIMI_SW;
-  if (run_decode_step(r, &probe, nullptr, nullptr) != 0) return 0;
+  if ((s->encoder ? run_encode_step(r, s, nullptr, nullptr) : run_decode_step(r, s, nullptr, nullptr)) != 0) return 0;
   return r.used + 256;
 }
-// One frame of codes [B][nq] int32 -> pcm [B][samples_per_frame] float32; the stream's state lives in `s` (library-owned device memory).
-// B is fixed by the first step after create / reset.  fp32 kernels.
+static int step_check(kk_mimi_stream* s, bool encoder, int B, const void* in, void* workspace, size_t workspace_bytes, void* out, const char* who) {
+  if (!s || !in || !workspace || !out || B < 1 || B > s->max_batch) return kk_fail(who, ": bad argument");
+  if (s->encoder != encoder) return kk_fail(who, ": the stream was created for the other direction");
+  if (s->frames > 0 && B != s->B) return kk_fail(who, ": the batch size of a stream is fixed until it is reset");
+  if (workspace_bytes < kk_mimi_stream_workspace_bytes(s, B)) return kk_fail(who, ": workspace too small");
+  return 0;
+}
+// chunk frames of codes [B][nq][chunk] int32 -> pcm [B][chunk * samples_per_frame] float32; the stream's state lives in `s`
+// (library-owned device memory).  B is fixed by the first step after create / reset.  fp32 kernels.
 extern "C" int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out) {
-  if (!s || !codes || !workspace || !pcm_out || B < 1 || B > s->max_batch) return kk_fail("kk_mimi_decode_step: bad argument");
-  if (s->frames > 0 && B != s->B) return kk_fail("kk_mimi_decode_step: the batch size of a stream is fixed until it is reset");
-  if (workspace_bytes < kk_mimi_stream_workspace_bytes(s, B)) return kk_fail("kk_mimi_decode_step: workspace too small");
+  MM_TRY(step_check(s, false, B, codes, workspace, workspace_bytes, pcm_out, "kk_mimi_decode_step"));
   s->B = B;
   s->m->dbg.clear();
   Run r{s->m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   r.adt = KK_F32;
   return run_decode_step(r, s, codes, pcm_out);
+}
+// Mimi.encode_step (mimi.py:156-161): pcm [B][chunk * samples_per_frame] float32 -> codes [B][nq][chunk] int32
+extern "C" int kk_mimi_encode_step(kk_mimi_stream* s, void* stream, int B, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out) {
+  MM_TRY(step_check(s, true, B, pcm, workspace, workspace_bytes, codes_out, "kk_mimi_encode_step"));
+  s->B = B;
+  s->m->dbg.clear();
+  Run r{s->m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
+  r.adt = KK_F32;
+  return run_encode_step(r, s, pcm, codes_out);
 }
 
 extern "C" int kk_mimi_encode_frames(const kk_mimi* m, int N) { return (m && N > 0) ? mimi_encode_frames(m->cfg, N) : 0; }

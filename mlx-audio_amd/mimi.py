@@ -69,14 +69,15 @@ class Mimi:
         self._h = h
         self._final = False
         self._ws = None
+        self._streams = {}
         if weights is not None:
             self.load_weights(weights)
 
     def __del__(self):
         try:
-            if getattr(self, "_sh", None) is not None:
-                self.lib.kk_mimi_stream_destroy(self._sh)
-                self._sh = None
+            for st in getattr(self, "_streams", {}).values():
+                self.lib.kk_mimi_stream_destroy(st["h"])
+            self._streams = {}
             if getattr(self, "_h", None):
                 self.lib.kk_mimi_destroy(self._h)
                 self._h = None
@@ -148,42 +149,79 @@ class Mimi:
                                           C.c_void_p(codes.data_ptr())), "kk_mimi_encode")
         return codes
 
-    # ---- streaming (mimi.py:163-168): one frame of codes per call, the state lives in a library-owned stream object
+    # ---- streaming (mimi.py:156-168): the state lives in library-owned stream objects, one per direction
+    def _open_stream(self, slot: str, encoder: bool, B: int, chunk: int, max_batch: int, max_frames: int):
+        """The stream of one direction; (re)created when the batch outgrows it or the chunk size changes (a fresh state either way)."""
+        st = self._streams.get(slot)
+        if st is None or st["maxb"] < B or st["chunk"] != chunk:
+            self._close_slot(slot)
+            h = C.c_void_p()
+            mb = max(B, max_batch)
+            check(self.lib.kk_mimi_stream_create_chunked(self._h, int(encoder), mb, max(max_frames, chunk), chunk, C.byref(h)), "kk_mimi_stream_create_chunked")
+            st = self._streams[slot] = {"h": h, "maxb": mb, "chunk": chunk, "ws": None}
+        need = int(self.lib.kk_mimi_stream_workspace_bytes(st["h"], B))
+        if need == 0:
+            raise KokoroHipError("kk_mimi_stream_workspace_bytes failed")
+        if st["ws"] is None or st["ws"].numel() < need:
+            st["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return st
+
     def decode_step(self, codes, max_batch: int = 0, max_frames: int = 2048) -> torch.Tensor:
-        """codes [B, nq, 1] -> pcm [B, 1, 1920].  The first call (or the first after reset_stream) fixes B."""
+        """codes [B, nq, F] -> pcm [B, 1, 1920 * F] (the reference feeds F = 1).  The first call (or the first after reset_stream) fixes B;
+        a call with another F starts a new stream."""
         if not self._final:
             raise KokoroHipError("Mimi.decode_step: load_weights first")
         codes = torch.as_tensor(codes).to(device=self.device, dtype=torch.int32)
-        if codes.ndim != 3 or codes.shape[1] != self.cfg.nq or codes.shape[2] != 1:
-            raise ValueError(f"codes must be [B, {self.cfg.nq}, 1], got {tuple(codes.shape)}")
-        B = codes.shape[0]
-        codes = codes[:, :, 0].contiguous()
+        if codes.ndim != 3 or codes.shape[1] != self.cfg.nq or codes.shape[2] < 1:
+            raise ValueError(f"codes must be [B, {self.cfg.nq}, F >= 1], got {tuple(codes.shape)}")
+        B, _, F = codes.shape
+        codes = codes.contiguous()
         with torch.cuda.device(self.device):
-            if getattr(self, "_sh", None) is None or self._s_maxb < B:
-                self.close_stream()
-                h = C.c_void_p()
-                check(self.lib.kk_mimi_stream_create(self._h, max(B, max_batch), max_frames, C.byref(h)), "kk_mimi_stream_create")
-                self._sh, self._s_maxb = h, max(B, max_batch)
-            need = int(self.lib.kk_mimi_stream_workspace_bytes(self._sh, B))
-            if need == 0:
-                raise KokoroHipError("kk_mimi_stream_workspace_bytes failed")
-            if getattr(self, "_sws", None) is None or self._sws.numel() < need:
-                self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            st = self._open_stream("dec", False, B, F, max_batch, max_frames)
             spf = int(self.lib.kk_mimi_samples_per_frame(self._h))
-            pcm = torch.empty((B, 1, spf), dtype=torch.float32, device=self.device)
+            pcm = torch.empty((B, 1, spf * F), dtype=torch.float32, device=self.device)
             self._last_B = B
-            check(self.lib.kk_mimi_decode_step(self._sh, self._stream(), B, C.c_void_p(codes.data_ptr()), C.c_void_p(self._sws.data_ptr()), self._sws.numel(),
+            check(self.lib.kk_mimi_decode_step(st["h"], self._stream(), B, C.c_void_p(codes.data_ptr()), C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),
                                                C.c_void_p(pcm.data_ptr())), "kk_mimi_decode_step")
         return pcm
 
+    def encode_step(self, xs, max_batch: int = 0, max_frames: int = 2048) -> torch.Tensor:
+        """mimi.py:156-161: pcm [B, 1, 1920 * F] -> codes [B, nq, F], continuing the encoder's state.  Whole code frames only (the
+        reference's modules also hold back a partial stride; a partial FRAME would return nothing until completed, so it is refused)."""
+        if not self._final:
+            raise KokoroHipError("Mimi.encode_step: load_weights first")
+        xs = torch.as_tensor(xs).to(device=self.device, dtype=torch.float32)
+        if xs.ndim != 3 or xs.shape[1] != 1:
+            raise ValueError(f"xs must be [B, 1, N], got {tuple(xs.shape)}")
+        spf = int(self.lib.kk_mimi_samples_per_frame(self._h))
+        B, _, N = xs.shape
+        if N < spf or N % spf:
+            raise ValueError(f"encode_step takes whole code frames ({spf} samples each), got {N} samples")
+        F = N // spf
+        xs = xs.reshape(B, N).contiguous()
+        with torch.cuda.device(self.device):
+            st = self._open_stream("enc", True, B, F, max_batch, max_frames)
+            codes = torch.empty((B, self.cfg.nq, F), dtype=torch.int32, device=self.device)
+            self._last_B = B
+            check(self.lib.kk_mimi_encode_step(st["h"], self._stream(), B, C.c_void_p(xs.data_ptr()), C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),
+                                               C.c_void_p(codes.data_ptr())), "kk_mimi_encode_step")
+        return codes
+
     def reset_stream(self) -> None:
-        if getattr(self, "_sh", None) is not None:
-            check(self.lib.kk_mimi_stream_reset(self._sh), "kk_mimi_stream_reset")
+        """Mimi.reset_state (mimi.py:131-137): both directions start over."""
+        for st in self._streams.values():
+            check(self.lib.kk_mimi_stream_reset(st["h"]), "kk_mimi_stream_reset")
+
+    reset_state = reset_stream
+
+    def _close_slot(self, slot: str) -> None:
+        st = self._streams.pop(slot, None)
+        if st is not None:
+            self.lib.kk_mimi_stream_destroy(st["h"])
 
     def close_stream(self) -> None:
-        if getattr(self, "_sh", None) is not None:
-            self.lib.kk_mimi_stream_destroy(self._sh)
-            self._sh = None
+        for slot in list(self._streams):
+            self._close_slot(slot)
 
     def debug_fetch(self, name: str) -> torch.Tensor:
         rows, ch = C.c_int64(0), C.c_int64(0)

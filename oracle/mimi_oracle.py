@@ -224,23 +224,27 @@ class MimiStreamOracle:
 
     def reset(self):
         self.state = {}
-        self.kv = [None] * self.cfg["num_layers"]
-        self.offset = 0
+        # mimi.py:129-130: one cache list per transformer (encoder_cache / decoder_cache), each with its own offset
+        self.kv = {"decoder_transformer": [None] * self.cfg["num_layers"], "encoder_transformer": [None] * self.cfg["num_layers"]}
+        self.offset = {"decoder_transformer": 0, "encoder_transformer": 0}
 
-    # conv.py:265-293 (stride 1, dilation 1 in the decoder)
-    def conv_step(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
+    # conv.py:265-293 (dilation 1 everywhere in Mimi): the first call left-pads ksize - stride (zeros, or the first sample for 'edge'),
+    # `_prev_xs` carries the unconsumed input, nframes = (len + stride - ksize) // stride outputs leave
+    def conv_step(self, x: torch.Tensor, prefix: str, stride: int = 1, pad_mode: str = "constant") -> torch.Tensor:
         w = t(self.o.w[prefix + ".conv.conv.weight"])
         b = t(self.o.w[prefix + ".conv.conv.bias"]) if prefix + ".conv.conv.bias" in self.o.w else None
         k = w.shape[1]
+        if x.shape[-1] == 0:
+            return x.new_zeros(x.shape[0], w.shape[0], 0)
         if prefix not in self.state:
-            x = F.pad(x, (k - 1, 0))
+            x = F.pad(x, (k - stride, 0), mode="replicate" if pad_mode == "edge" else "constant")
         else:
             x = torch.cat([self.state[prefix], x], dim=-1)
-        nframes = max(x.shape[-1] + 1 - k, 0)
-        self.state[prefix] = x[..., nframes:]
+        nframes = max(x.shape[-1] + stride - k, 0) // stride
+        self.state[prefix] = x[..., nframes * stride :]
         if nframes == 0:
             return x.new_zeros(x.shape[0], w.shape[0], 0)
-        return F.conv1d(x[..., : nframes - 1 + k], w.permute(0, 2, 1), b)
+        return F.conv1d(x[..., : (nframes - 1) * stride + k], w.permute(0, 2, 1), b, stride=stride)
 
     # conv.py:335-351
     def convtr_step(self, x: torch.Tensor, prefix: str, stride: int, depthwise: bool = False) -> torch.Tensor:
@@ -263,13 +267,14 @@ class MimiStreamOracle:
         self.state[prefix] = ys[..., ot - inv :]
         return ys[..., : ot - inv]
 
-    def transformer_step(self, x: torch.Tensor) -> torch.Tensor:
+    def transformer_step(self, x: torch.Tensor, which: str = "decoder_transformer") -> torch.Tensor:
         cfg, o = self.cfg, self.o
+        kv = self.kv[which]
         H = cfg["num_heads"]
         x = x.transpose(1, 2)
         Bn, T, C = x.shape
         hd = C // H
-        pos = torch.arange(self.offset, self.offset + T, dtype=torch.float32)[:, None]
+        pos = torch.arange(self.offset[which], self.offset[which] + T, dtype=torch.float32)[:, None]
         inv = torch.tensor(float(cfg["rope_base"]), dtype=torch.float32) ** (-torch.arange(0, hd // 2, dtype=torch.float32) / (hd // 2))
         c, s = torch.cos(pos * inv[None]), torch.sin(pos * inv[None])
 
@@ -280,15 +285,15 @@ class MimiStreamOracle:
             return out
 
         for i in range(cfg["num_layers"]):
-            p = f"decoder_transformer.transformer.layers.{i}"
+            p = f"{which}.transformer.layers.{i}"
             n1 = F.layer_norm(x, (C,), t(o.w[p + ".norm1.weight"]), t(o.w[p + ".norm1.bias"]), 1e-5)
             qkv = (n1 @ t(o.w[p + ".self_attn.in_proj.weight"]).T).reshape(Bn, T, 3, H, hd)
             q, k, v = [qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3)]
             q, k = rope(q), rope(k)
-            if self.kv[i] is not None:
-                k = torch.cat([self.kv[i][0], k], dim=2)
-                v = torch.cat([self.kv[i][1], v], dim=2)
-            self.kv[i] = (k, v)
+            if kv[i] is not None:
+                k = torch.cat([kv[i][0], k], dim=2)
+                v = torch.cat([kv[i][1], v], dim=2)
+            kv[i] = (k, v)
             klen = k.shape[2]
             tgt = T + min(self.context, klen - T)
             k, v = k[:, :, klen - tgt :], v[:, :, klen - tgt :]
@@ -299,7 +304,7 @@ class MimiStreamOracle:
             h = n2 @ t(o.w[p + ".gating.linear1.weight"]).T
             h = 0.5 * h * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (h + 0.044715 * h ** 3)))
             x = x + (h @ t(o.w[p + ".gating.linear2.weight"]).T) * t(o.w[p + ".layer_scale_2.scale"])
-        self.offset += T
+        self.offset[which] += T
         return x.transpose(1, 2)
 
     def seanet_step(self, x: torch.Tensor) -> torch.Tensor:
@@ -321,6 +326,33 @@ class MimiStreamOracle:
             xt = self.transformer_step(x)
             pcm = self.seanet_step(xt).numpy()
         return (pcm, {"upsampled": x.numpy(), "transformer": xt.numpy()}) if return_inter else pcm
+
+    # seanet.py:120-212 through each module's step (SeaNetEncoder.step: init conv, per layer residual block + ELU + strided conv, last conv)
+    def seanet_encoder_step(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.conv_step(x, "encoder.init_conv1d")
+        for l, r in enumerate(reversed(self.cfg["ratios"])):
+            p = f"encoder.layers.{l}"
+            res = x
+            y = self.conv_step(F.elu(x), p + ".residuals.0.block.0")
+            y = self.conv_step(F.elu(y), p + ".residuals.0.block.1")
+            x = y + res
+            x = self.conv_step(F.elu(x), p + ".downsample", stride=r)
+        return self.conv_step(F.elu(x), "encoder.final_conv1d")
+
+    def encode_step(self, pcm: np.ndarray, return_inter: bool = False):
+        """Mimi.encode_step (mimi.py:156-161): pcm [B, 1, n] -> codes [B, nq, frames completed by this call] (whole strides only leave
+        each module; the rest waits in its `_prev_xs`)."""
+        with torch.no_grad():
+            x = self.seanet_encoder_step(t(pcm))
+            xt = self.transformer_step(x, "encoder_transformer") if x.shape[-1] else x
+            xd = self.conv_step(xt, "downsample.conv", stride=self.cfg["upsample_stride"], pad_mode="edge")
+            if xd.shape[-1] == 0:
+                codes = np.zeros((pcm.shape[0], self.cfg["nq"], 0), np.int64)
+            else:
+                codes = self.o.rvq_encode("rvq_first", xd, 1)
+                if self.cfg["nq"] > 1:
+                    codes = np.concatenate([codes, self.o.rvq_encode("rvq_rest", xd, self.cfg["nq"] - 1)], axis=1)
+        return (codes, {"seanet": x.numpy(), "transformer": xt.numpy(), "downsampled": xd.numpy()}) if return_inter else codes
 
     def decode_frames(self, codes: np.ndarray) -> np.ndarray:
         return np.concatenate([self.decode_step(codes[:, :, i : i + 1]) for i in range(codes.shape[-1])], axis=-1)

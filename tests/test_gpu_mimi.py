@@ -176,8 +176,9 @@ def test_mimi_golden_fixture_without_oracle():
 @pytest.mark.parametrize("which", ["tiny", "mimi_202407"])
 def test_mimi_streaming_decode_matches_stream_oracle(which):
     """Mimi.decode_step / MimiStreamingDecoder (mimi.py:163-168,264-306) through kk_mimi_decode_step against MimiStreamOracle (the
-    reference's explicit conv / cache state): every frame's pcm within 1e-3 (fp32: measured ~1e-6), more frames than the output window
-    holds (the window slides), more cached positions than the tiny context (the key range slides), reset, and batch independence."""
+    reference's explicit conv / cache state): every frame's pcm within 1e-3 (fp32: measured ~1e-6) with per-layer carried rows (more
+    frames than any module's look-back), more cached positions than the tiny context (the key range slides), reset, batch independence,
+    and several frames per step."""
     from mlx_audio_amd.mimi import Mimi, MimiConfig, MimiStreamingDecoder
 
     cfg = P.mimi_tiny_config() if which == "tiny" else P.mimi_config(32)
@@ -213,13 +214,63 @@ def test_mimi_streaming_decode_matches_stream_oracle(which):
     # streaming is NOT decode(): the offline transformer sees the whole sequence (no mask), the stream only the past
     off = model.decode(torch.tensor(codes)).cpu().numpy()
     assert np.abs(off - again).max() > 1e-4
+    # three frames per step: the reference's modules take any length; the positions of one step see each other, so this is its own stream
+    dec.reset()
+    orc3 = M.MimiStreamOracle(w, cfg)
+    for i in range(0, Nf - Nf % 3, 3):
+        ref3 = orc3.decode_step(codes[:, :, i : i + 3])
+        got3 = model.decode_step(torch.tensor(codes[:, :, i : i + 3])).cpu().numpy()
+        e = err_stats(got3, ref3)
+        assert got3.shape == ref3.shape and e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), (i, e)
     if which == "tiny":  # a context shorter than the history: the key range slides (transformer.py:94-98)
+        model.decode_step(torch.tensor(codes[:, :, :1]))  # back to the one-frame stream (a new chunk size opens a fresh one)
         from mlx_audio_amd import _lib
 
         dec.reset()
-        _lib.check(model.lib.kk_mimi_stream_set_context(model._sh, 6), "set_context")
+        _lib.check(model.lib.kk_mimi_stream_set_context(model._streams["dec"]["h"], 6), "set_context")
         short = dec.decode_frames(torch.tensor(codes)).cpu().numpy()
         ref_short = M.MimiStreamOracle(w, cfg, context=6).decode_frames(codes)
         e = err_stats(short, ref_short)
         report("mimi/stream/tiny_context6", **e)
         assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]) and np.abs(short - again).max() > 1e-4
+
+
+@pytest.mark.parametrize("which", ["tiny", "mimi_202407"])
+def test_mimi_streaming_encode_matches_stream_oracle(which):
+    """Mimi.encode_step (mimi.py:156-161) through kk_mimi_encode_step against MimiStreamOracle.encode_step: the SEANet encoder rows and
+    the transformer rows of every chunk within 2e-4 (fp32), codes identical up to near-tie flips of the argmin; one and two frames per
+    step; reset; a partial frame is refused."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+
+    cfg = P.mimi_tiny_config() if which == "tiny" else P.mimi_config(32)
+    w = P.mimi_synth_checkpoint(cfg, 5, encode=True)
+    spf = 1920 if which != "tiny" else int(np.prod(cfg["ratios"])) * cfg["upsample_stride"]
+    B, Nf = (2, 12) if which == "tiny" else (2, 6)
+    rng = np.random.default_rng(11)
+    pcm = (rng.standard_normal((B, 1, Nf * spf)) * 0.3).astype(np.float32)
+    model = Mimi(MimiConfig.from_dict(cfg), w)
+    for F in (1, 2):
+        orc = M.MimiStreamOracle(w, cfg)
+        model.reset_stream()
+        got_all, ref_all = [], []
+        for i in range(0, Nf, F):
+            ref, inter = orc.encode_step(pcm[..., i * spf : (i + F) * spf], return_inter=True)
+            got = model.encode_step(torch.tensor(pcm[..., i * spf : (i + F) * spf]))
+            torch.cuda.synchronize()
+            assert tuple(got.shape) == (B, cfg["nq"], F) == ref.shape
+            for name in ("seanet", "transformer", "downsampled"):
+                e = err_stats(model.debug_fetch(name).cpu().numpy(), np.transpose(inter[name], (0, 2, 1)))
+                assert e["rel_max"] < 2e-4, (F, i, name, e)
+            got_all.append(got.cpu().numpy()); ref_all.append(ref)
+        got_all, ref_all = np.concatenate(got_all, -1), np.concatenate(ref_all, -1)
+        agree = float((got_all == ref_all).mean())
+        report(f"mimi/stream_encode/{which}/F{F}", agree=agree)
+        assert agree > 0.97
+        if F == 1:
+            first = got_all
+    model.reset_stream()
+    again = np.concatenate([model.encode_step(torch.tensor(pcm[..., i * spf : (i + 2) * spf])).cpu().numpy() for i in range(0, Nf, 2)], -1)
+    np.testing.assert_array_equal(again, got_all)
+    assert first.shape == again.shape
+    with pytest.raises(ValueError):
+        model.encode_step(torch.tensor(pcm[..., : spf + 5]))

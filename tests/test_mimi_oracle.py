@@ -105,3 +105,44 @@ def test_streaming_restatement_properties():
     short = M.MimiStreamOracle(w, cfg, context=4).decode_frames(codes)
     np.testing.assert_array_equal(short[..., : 3 * one.shape[-1]], pcm_st[..., : 3 * one.shape[-1]])
     assert np.abs(short - pcm_st).max() > 0
+
+
+def test_streaming_encode_restatement_properties():
+    """MimiStreamOracle.encode_step (Mimi.encode_step, mimi.py:156-161, through StreamableConv1d.step, conv.py:265-293): the causal
+    SEANet encoder and the 'edge' resampler give, chunk by chunk, what the offline causal convolutions give on whole frames (for the
+    convolutions chunk boundaries do not matter, not even ragged ones: every module holds back its partial stride), while the encoder transformer with its
+    cache sees the past only, so codes differ from encode() beyond the first chunk."""
+    import torch
+
+    cfg = P.mimi_tiny_config()
+    w = P.mimi_synth_checkpoint(cfg, 0, encode=True)
+    spf = int(np.prod(cfg["ratios"])) * cfg["upsample_stride"]
+    rng = np.random.default_rng(1)
+    pcm = (rng.standard_normal((2, 1, 6 * spf)) * 0.3).astype(np.float32)
+    off = M.MimiOracle(w, cfg)
+    _, inter = off.encode(pcm, return_inter=True)
+    st = M.MimiStreamOracle(w, cfg)
+    sea, trs, cds = [], [], []
+    for i in range(6):
+        c, it = st.encode_step(pcm[..., i * spf : (i + 1) * spf], return_inter=True)
+        assert c.shape == (2, cfg["nq"], 1)
+        sea.append(it["seanet"]); trs.append(it["transformer"]); cds.append(c)
+    np.testing.assert_allclose(np.concatenate(sea, -1), inter["seanet"], atol=2e-6 * max(1.0, float(np.abs(inter["seanet"]).max())))
+    # the resampler + quantiser of the streamed transformer rows, run offline, give the streamed codes
+    with torch.no_grad():
+        xd = off.strided_causal_conv(torch.tensor(np.concatenate(trs, -1)), "downsample.conv", cfg["upsample_stride"], pad_mode="edge")
+        again = off.rvq_encode("rvq_first", xd, 1)
+        if cfg["nq"] > 1:
+            again = np.concatenate([again, off.rvq_encode("rvq_rest", xd, cfg["nq"] - 1)], axis=1)
+    assert (again == np.concatenate(cds, -1)).mean() > 0.98  # near-tie flips of the argmin aside
+    # ragged chunks (not whole frames): the same SEANet rows and the same NUMBER of frames come out, later; the codes may differ, because
+    # the positions one transformer step holds see each other (no mask) and the chunking decides which those are
+    st.reset()
+    cuts = [0, 7, spf + 3, 2 * spf, 4 * spf - 1, 6 * spf]
+    rag = [st.encode_step(pcm[..., a:b], return_inter=True) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.concatenate([c for c, _ in rag], -1).shape == (2, cfg["nq"], 6)
+    np.testing.assert_allclose(np.concatenate([it["seanet"] for _, it in rag], -1), inter["seanet"], atol=2e-6 * max(1.0, float(np.abs(inter["seanet"]).max())))
+    # one chunk holding everything: the transformer sees all positions at once, as encode() does
+    st.reset()
+    whole = st.encode_step(pcm)
+    assert (whole == off.encode(pcm)).mean() > 0.98
