@@ -450,7 +450,7 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         try:
             # PMC byte counts were taken at one batch size per configuration: B = 32 for the bf16 / fp32 entries, B = 64 for config 5
             key, pmc_batch = ("bfloat16+fp8 (config 5, B=64, r01_i)", 64) if (args.quantized and quantization_kernel == "mxfp8") else (args.dtype, 32)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(key) if B == pmc_batch else None
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(key) if B == pmc_batch else None
         except Exception:
             pmc = None
         if prof is not None:
@@ -460,7 +460,7 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
             traffic = None
             if pmc and conv is prof["conv_mfma"] and "conv_mfma" in pmc:
-                c = pmc["conv_mfma"]  # separate --pmc passes, see profiles/r01_pmc_traffic.json (read side reported raw)
+                c = pmc["conv_mfma"]  # separate --pmc passes, see profiles/r02_pmc_traffic.json (read side reported raw)
                 traffic = (c["fetch_raw_bytes_per_step"] + c["write_bytes_per_step"]) / c["launches_per_step"]
             if prof.get("linear_mxfp8", {}).get("ms", 0) > 0:
                 q = prof["linear_mxfp8"]  # activation pre-pass + block-scaled fp8 product, bracketed together
@@ -479,7 +479,7 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
                 tr = None
                 if pmc and "istft_head" in pmc:
                     tr = pmc["istft_head"]["fetch_corrected_bytes_per_launch"] + pmc["istft_head"]["write_bytes_per_launch"]
-                out["roofline_istft_head"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                out["roofline_istft_head"] = {"bound": "hbm", "kernel": "conv_post_istft (conv_post + iSTFT + overlap-add fused; stand-alone iSTFT head in fp32 mode)", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                               "traffic": tr, "us_per_launch": ih["ms"] / ih["launches"] * 1e3}
             out["launch_mode"] = "hipGraph replay" if use_graph else "eager"
             out["ms_per_step_eager_profiled_pass"] = dt_prof / args.steps * 1e3
