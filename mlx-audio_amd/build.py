@@ -22,7 +22,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++
 
 # per-file extras.  kk_source.hip: the iSTFT head is written on explicit register pairs (v_pk_*_f32); hipcc's SLP vectoriser otherwise
 # re-pairs the scalar tail across outputs and pays two v_mov per packed op it creates
-FILE_FLAGS = {"kk_source.hip": ["-fno-slp-vectorize"], "kk_head.hip": ["-fno-slp-vectorize"], "kk_conv_mfma5.hip": ["-fno-slp-vectorize"], "kk_conv_mfma4.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"kk_source.hip": ["-fno-slp-vectorize"], "kk_head.hip": ["-fno-slp-vectorize"], "kk_conv_mfma5.hip": ["-fno-slp-vectorize"], "kk_conv_mfma4.hip": ["-fno-slp-vectorize"], "kk_conv_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

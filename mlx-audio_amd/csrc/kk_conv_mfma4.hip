@@ -30,20 +30,12 @@
 
 #include "kk_common.h"
 #include "kk_kernels.h"
+#include "kk_conv_mfma_shared.h"
 
 #define TR_NOW() 0ull
 #define TR_ADD(slot, v) do { } while (0)
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// Two floats WITHOUT the packed-f32 instructions (v_pk_fma_f32 ...): beside another wave's MFMAs on the same SIMD the packed forms run at
-// about half rate (variant 5's service waves showed it first; here 2-6 % per fused launch).  Built with -fno-slp-vectorize for the same reason.
-struct v2f {
-  float x, y;
-};
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ v2f& operator+=(v2f& a, v2f b) { a.x += b.x; a.y += b.y; return a; }
-__device__ __forceinline__ v2f& operator*=(v2f& a, v2f b) { a.x *= b.x; a.y *= b.y; return a; }
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -66,7 +58,6 @@ struct Geo {
   static constexpr int XREG = (XROWS * 8 + 255) / 256;  // 16-byte chunks of the slab per thread
 };
 
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 union U16 {
   uint4 u;
@@ -149,122 +140,7 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
     const int lin_hi = Lin > 0 ? Lin - 1 : 0;
     const int cin_real = a.Cin > 0 ? a.Cin : a.CinP;
 
-    uint4 xreg[XREG];
-    float4 preg = make_float4(0.f, 0.f, 0.f, 0.f);  // threads 0..47: one float4 of the slab's A | B | alpha
-    unsigned xok = 0;
-
-    auto load_x = [&](int chunk) __attribute__((always_inline)) {
-      xok = 0;
-      // parameter loads go FIRST: vmcnt retires in order, so storing them to LDS one tap later does not wait for the slab
-      if (NRM && tid < 48) {
-        const int which = tid >> 4, c = chunk * CK + (tid & 15) * 4;
-        if (which == 0) preg = *(const float4*)(a.nrm_a + (long long)b * a.nrm_stride + c);
-        else if (which == 1) preg = *(const float4*)(a.nrm_b + (long long)b * a.nrm_stride + c);
-        else if (NRM == 1) {
-          preg.x = (c + 0) < a.nrm_C ? a.nrm_alpha[c + 0] : 1.0f;
-          preg.y = (c + 1) < a.nrm_C ? a.nrm_alpha[c + 1] : 1.0f;
-          preg.z = (c + 2) < a.nrm_C ? a.nrm_alpha[c + 2] : 1.0f;
-          preg.w = (c + 3) < a.nrm_C ? a.nrm_alpha[c + 3] : 1.0f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < XREG; ++i) {
-        const int id = i * 256 + tid;
-        const int r = id >> 3, c8 = (id & 7) * 8;
-        int row = q0 + min_off + r;
-        const bool ok0 = row >= 0 && r < xrows;
-        if (a.in_shift) row >>= a.in_shift;
-        if (ok0 && row < Lin) xok |= 1u << i;
-        const int rc = row < 0 ? 0 : (row > lin_hi ? lin_hi : row);
-        xreg[i] = *(const uint4*)(xb + (long long)rc * a.ldx + chunk * CK + c8);
-      }
-      asm volatile("" ::: "memory");
-    };
-    auto store_p = [&](int chunk) __attribute__((always_inline)) {
-      if (NRM && tid < 48) *(float4*)(Ps + (chunk & 1) * 3 * CK + (tid >> 4) * CK + (tid & 15) * 4) = preg;
-    };
-    auto store_x = [&](int chunk) __attribute__((always_inline)) {
-      // value barrier: without it hipcc hoists the first unpack instructions of this function up to the loads in load_x
-      // (one k-slab earlier) and waits for the slab there, which turns the prefetch into a synchronous load
-#pragma unroll
-      for (int i = 0; i < XREG; ++i) asm volatile("" : "+v"(xreg[i].x), "+v"(xreg[i].y), "+v"(xreg[i].z), "+v"(xreg[i].w));
-      if (NRM) {
-        // y = act(x * A + B): AdaIN1d + Snake / LeakyReLU (istftnet.py:333-337,382) applied while staging.  This thread's 8
-        // channels are the same for all its rows ((id & 7) == (tid & 7)); they are handled one packed PAIR at a time so that
-        // only 8 parameter registers are live, and the loop body is branch-free (the activation is a template parameter) so
-        // the transcendental latency of neighbouring elements overlaps.
-        const float* pt = Ps + (chunk & 1) * 3 * CK + (tid & 7) * 8;
-        const float slope = a.nrm_slope;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const float a0 = pt[2 * kk], a1 = pt[2 * kk + 1], b0 = pt[CK + 2 * kk], b1 = pt[CK + 2 * kk + 1];
-          float l0 = 0.f, l1 = 0.f, i0 = 0.f, i1 = 0.f;
-          if (NRM == 1) {  // snake: y + sin^2(alpha y) / alpha; v_sin_f32 takes revolutions
-            const float al0 = pt[2 * CK + 2 * kk], al1 = pt[2 * CK + 2 * kk + 1];
-            l0 = al0 * 0.15915494309189535f;
-            l1 = al1 * 0.15915494309189535f;
-            i0 = __builtin_amdgcn_rcpf(al0);
-            i1 = __builtin_amdgcn_rcpf(al1);
-          }
-#pragma unroll
-          for (int i = 0; i < XREG; ++i) {
-            const unsigned wd = kk == 0 ? xreg[i].x : kk == 1 ? xreg[i].y : kk == 2 ? xreg[i].z : xreg[i].w;
-            float y0 = __builtin_fmaf(__uint_as_float(wd << 16), a0, b0);
-            float y1 = __builtin_fmaf(__uint_as_float(wd & 0xFFFF0000u), a1, b1);
-            if (NRM == 1) {
-              const float s0 = __builtin_amdgcn_sinf(l0 * y0), s1 = __builtin_amdgcn_sinf(l1 * y1);
-              y0 = __builtin_fmaf(i0 * s0, s0, y0);
-              y1 = __builtin_fmaf(i1 * s1, s1, y1);
-            } else {
-              y0 = y0 > 0.f ? y0 : y0 * slope;
-              y1 = y1 > 0.f ? y1 : y1 * slope;
-            }
-            const bf16x2 pk = {(bf16_t)y0, (bf16_t)y1};
-            const unsigned o = __builtin_bit_cast(unsigned, pk);
-            if (kk == 0) xreg[i].x = o;
-            else if (kk == 1) xreg[i].y = o;
-            else if (kk == 2) xreg[i].z = o;
-            else xreg[i].w = o;
-          }
-        }
-      }
-      // this thread's 8 channels are the same for all its rows; channels >= Cin are pad and may hold anything (NaN x 0 = NaN)
-      const int cfirst = chunk * CK + (tid & 7) * 8;
-      unsigned cm[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cm[j] = (cfirst + 2 * j < cin_real ? 0x0000FFFFu : 0u) | (cfirst + 2 * j + 1 < cin_real ? 0xFFFF0000u : 0u);
-#pragma unroll
-      for (int i = 0; i < XREG; ++i) {
-        const int id = i * 256 + tid;
-        const int r = id >> 3, c8 = (id & 7) * 8;
-        if (r < xrows) {
-          const unsigned msk = (xok >> i) & 1u ? 0xFFFFFFFFu : 0u;
-          // padding rows / pad channels stay exactly zero.  32-bit integer ops only: touching the slab registers as bf16
-          // ELEMENTS makes hipcc split them into 16-bit pieces right at the loads (and wait for the loads there)
-          unsigned wq[4] = {xreg[i].x & msk & cm[0], xreg[i].y & msk & cm[1], xreg[i].z & msk & cm[2], xreg[i].w & msk & cm[3]};
-          if (NRM == 0 && a.in_act == KK_ACT_ELU) {  // nn.elu: where(x > 0, x, exp(x) - 1); elu(0) = 0 keeps the padding zero
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              float lo = __uint_as_float(wq[k] << 16), hi = __uint_as_float(wq[k] & 0xFFFF0000u);
-              lo = lo > 0.f ? lo : __expf(lo) - 1.0f;
-              hi = hi > 0.f ? hi : __expf(hi) - 1.0f;
-              const bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
-              wq[k] = __builtin_bit_cast(unsigned, pk);
-            }
-          } else if (a.in_slope != 1.0f) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              float lo = __uint_as_float(wq[k] << 16), hi = __uint_as_float(wq[k] & 0xFFFF0000u);
-              lo = lo > 0.f ? lo : lo * a.in_slope;
-              hi = hi > 0.f ? hi : hi * a.in_slope;
-              const bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
-              wq[k] = __builtin_bit_cast(unsigned, pk);
-            }
-          }
-          *(uint4*)(Xs + r * XLD + c8) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-        }
-      }
-    };
+#include "kk_conv_mfma_stage.h"  // xreg / preg / xok, load_x, store_p, store_x (shared with variant 2)
     // B fragments of one (tap, slab) iteration: [ni][ks], loaded from the fragment-order pack one iteration ahead.  Named
     // scalars, not an array (hipcc put a lambda-captured register array in scratch once already).
     uint4 q00, q01, q02, q03, q10, q11, q12, q13;
@@ -346,220 +222,7 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
     __syncthreads();  // main-loop LDS is dead; the epilogue tile aliases it
   }
 
-  // ---- epilogue: per 128 rows, accumulators -> fp32 LDS tile -> coalesced rows --------------------------------------
-  TO* ob = (TO*)a.out + (long long)b * a.obs;
-  const TO* rb = a.res ? (const TO*)a.res + (long long)b * a.rbs : nullptr;
-  const int n = n0 + (tid & 15) * 8;  // this thread's 8 output channels (same for all its rows)
-  const int nc = n < a.Cout ? n : 0;  // clamped for the unconditional loads
-  const int lo_hi = a.Lo_rows - 1;
-  constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
-  v2f bias2[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)  // bias has CoutP entries
-    bias2[k] = a.bias ? v2f{a.bias[n0 + (tid & 15) * 8 + 2 * k], a.bias[n0 + (tid & 15) * 8 + 2 * k + 1]} : v2f{0.f, 0.f};
-  const v2f scale2 = {a.scale, a.scale}, act_slope2 = {a.act_slope, a.act_slope};
-  v2f st_s[4], st_q[4];  // column sums / sums of squares of the values this thread stores (pairs of adjacent columns)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) st_s[k] = st_q[k] = v2f{0.f, 0.f};
-
-  constexpr int RPP = G::RPP, NPASS = BM / RPP, TASKS = RPP * 16 / 256, TG = TASKS / 2;  // 8 or 6 row tasks per thread and pass
-  // bf16 residual rows of the WHOLE tile are requested up front (xreg / w registers are dead by now): one exposed HBM
-  // round trip per tile instead of one per (pass, half)
-  constexpr bool PRE = sizeof(TO) == 2;
-  uint4 rpre[PRE ? NPASS * 2 * TG : 1];
-  if (PRE && rb) {
-#pragma unroll
-    for (int j = 0; j < NPASS * 2 * TG; ++j) {
-      const int q = q0 + (j / (2 * TG)) * RPP + (((j % (2 * TG)) * 256 + tid) >> 4);
-      const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
-      const int opc = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
-      rpre[j] = *(const uint4*)(rb + (long long)opc * a.ldr + nc);
-    }
-    asm volatile("" ::: "memory");
-  }
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    if (tile_live) {
-      if (pass > 0) __syncthreads();  // previous pass's readers are done with Cs
-      // rows [RPP*pass, RPP*pass + RPP) of the block tile: tall tiles -> wave row `pass`; 128-row tile -> both wave rows
-      if (wr == pass) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const int col = wc * 64 + ni * 32 + (lane & 31);
-            const int rbase = mi * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];
-          }
-      }
-      __syncthreads();
-    }
-    if (pass == 0) TR_ADD(6, TR_NOW() - tr0);  // .. first accumulator tile is in LDS (residual requests issued)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      int opv[TG];
-      bool wr_ok[TG], live[TG];
-      uint4 rres[TG][VEC], rold[TG][VEC];
-#pragma unroll
-      for (int i = 0; i < TG; ++i) {
-        const int row = ((half * TG + i) * 256 + tid) >> 4;
-        const int q = q0 + pass * RPP + row;
-        const int op = a.mode == KK_CONV ? q : phase + a.stride * q;
-        opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
-        wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
-        live[i] = tile_live && op < Lout;
-      }
-      if (rb) {  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < TG; ++i) {
-          if (PRE) rres[i][0] = rpre[(pass * 2 + half) * TG + i];
-          else
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) rres[i][v] = *((const uint4*)(rb + (long long)opv[i] * a.ldr + nc) + v);
-        }
-      }
-      if (a.accumulate) {
-#pragma unroll
-        for (int i = 0; i < TG; ++i)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) rold[i][v] = *((const uint4*)(ob + (long long)opv[i] * a.ldo + nc) + v);
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < TG; ++i) {
-        // the element-wise chain runs on float PAIRS (v_pk_add/mul/fma_f32: two lanes of fp32 per instruction, same IEEE
-        // results as the scalar form); bf16 <-> fp32 widening is a shift / mask on the packed word
-        const int row = ((half * TG + i) * 256 + tid) >> 4;
-        v2f v[4];
-        if (tile_live) {
-          const float4 c0 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8);
-          const float4 c1 = *(const float4*)(Cs + row * CLD + (tid & 15) * 8 + 4);
-          v[0] = v2f{c0.x, c0.y}; v[1] = v2f{c0.z, c0.w}; v[2] = v2f{c1.x, c1.y}; v[3] = v2f{c1.z, c1.w};
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += bias2[k];
-        if (a.act == KK_ACT_LRELU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const v2f m = v[k] * act_slope2;
-            v[k].x = v[k].x > 0.f ? v[k].x : m.x;
-            v[k].y = v[k].y > 0.f ? v[k].y : m.y;
-          }
-        } else if (a.act == KK_ACT_GELU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k].x = gelu_exact(v[k].x);
-            v[k].y = gelu_exact(v[k].y);
-          }
-        } else if (NRM == 0 && a.act == KK_ACT_GELU_TANH) {  // nn.gelu_approx (plain variant only: keeps the fused variants' registers)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k].x = 0.5f * v[k].x * (1.0f + tanhf(0.7978845608028654f * (v[k].x + 0.044715f * (v[k].x * v[k].x * v[k].x))));
-            v[k].y = 0.5f * v[k].y * (1.0f + tanhf(0.7978845608028654f * (v[k].y + 0.044715f * (v[k].y * v[k].y * v[k].y))));
-          }
-        }
-        if (rb) {
-          if (sizeof(TO) == 2) {
-            const unsigned w4[4] = {rres[i][0].x, rres[i][0].y, rres[i][0].z, rres[i][0].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
-          } else {
-            U32x8 t;
-            t.u[0] = rres[i][0];
-            t.u[1] = rres[i][VEC - 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= scale2;
-        if (a.accumulate) {
-          if (sizeof(TO) == 2) {
-            const unsigned w4[4] = {rold[i][0].x, rold[i][0].y, rold[i][0].z, rold[i][0].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
-          } else {
-            U32x8 t;
-            t.u[0] = rold[i][0];
-            t.u[1] = rold[i][VEC - 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
-          }
-        }
-        if (sizeof(TO) == 2) {
-          const unsigned lm = live[i] ? 0xFFFFFFFFu : 0u;  // rows past the utterance are stored as exact zeros
-          unsigned w4[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bf16x2 pk = {(bf16_t)v[k].x, (bf16_t)v[k].y};
-            w4[k] = __builtin_bit_cast(unsigned, pk) & lm;
-          }
-          if (wr_ok[i]) {
-            *(uint4*)(ob + (long long)opv[i] * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const v2f r = {__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
-                st_s[k] += r;
-                st_q[k] = fma2(r, r, st_q[k]);
-              }
-            }
-          }
-        } else {
-          if (!live[i]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
-          }
-          if (wr_ok[i]) {
-            float* dst = (float*)(ob + (long long)opv[i] * a.ldo + n);
-            *(float4*)dst = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-            *(float4*)(dst + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
-          }
-        }
-      }
-    }
-    if (pass == 0) TR_ADD(7, TR_NOW() - tr0);  // .. first pass stored
-  }
-  TR_ADD(4, TR_NOW() - tr0);  // start .. end of the store phase
-  TR_ADD(5, 1);
-  if (a.stat_part) {
-    // rows of one column group live in threads tid = rg*16 + cg: reduce rg over the wave by shuffles (xor 16, 32),
-    // then over the 4 waves through LDS; one deterministic partial per (utterance, tile, column)
-    __syncthreads();  // every wave is done reading the Cs tile
-    float* red = (float*)smem;  // [4 waves][2][128]
-    float ss[8], sq[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ss[2 * k] = st_s[k].x; ss[2 * k + 1] = st_s[k].y;
-      sq[2 * k] = st_q[k].x; sq[2 * k + 1] = st_q[k].y;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      ss[k] += __shfl_xor(ss[k], 16);
-      ss[k] += __shfl_xor(ss[k], 32);
-      sq[k] += __shfl_xor(sq[k], 16);
-      sq[k] += __shfl_xor(sq[k], 32);
-    }
-    if (lane < 16) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        red[(wave * 2 + 0) * 128 + lane * 8 + k] = ss[k];
-        red[(wave * 2 + 1) * 128 + lane * 8 + k] = sq[k];
-      }
-    }
-    __syncthreads();
-    const int which = tid >> 7, col = tid & 127;  // threads 0..127 -> sums, 128..255 -> sums of squares
-    if (n0 + col < a.Cout) {
-      const float v = red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col] + red[(2 * 2 + which) * 128 + col] +
-                      red[(3 * 2 + which) * 128 + col];
-      const int tile = bx * nphase + phase;
-      a.stat_part[(((long long)b * a.stat_ntiles + tile) * 2 + which) * a.Cout + n0 + col] = v;
-    }
-  }
+#include "kk_conv_mfma_epilogue.h"  // (shared with variant 2)
 }
 
 template <typename TO, int WM, int NRM>

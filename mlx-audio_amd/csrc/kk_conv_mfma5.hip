@@ -21,6 +21,7 @@
 
 #include "kk_common.h"
 #include "kk_kernels.h"
+#include "kk_conv_mfma_shared.h"
 
 #ifdef KK_MFMA_TRACE
 // phase timing (python mlx-audio_amd/build.py --trace; never compiled into the shipped library): cycles of wave 0 (MFMA role) and wave 4
@@ -51,15 +52,6 @@ extern "C" int kk_debug_mfma5_trace(unsigned long long* out8, int reset) {
 #endif
 namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// Two floats WITHOUT the packed-f32 instructions (v_pk_fma_f32 ...): measured beside the MFMA wave of the same SIMD they run at half rate
-// (the file is built with -fno-slp-vectorize for the same reason).
-struct v2f {
-  float x, y;
-};
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ v2f& operator+=(v2f& a, v2f b) { a.x += b.x; a.y += b.y; return a; }
-__device__ __forceinline__ v2f& operator*=(v2f& a, v2f b) { a.x *= b.x; a.y *= b.y; return a; }
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -77,7 +69,6 @@ constexpr int LDS5_BYTES = XS_BYTES + CS_BYTES + RED_BYTES + 2 * MAX_B5 * 4 + 2 
 constexpr int XREG = (XROWS * 8 + 255) / 256;  // 16-byte chunks of the slab per service thread
 constexpr int NTASK = BM * 16 / 256;           // epilogue row tasks per service thread and tile (12)
 
-__device__ __forceinline__ float gelu_exact5(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // raw workgroup barrier: LDS traffic of this wave is complete, global loads / stores stay in flight
 #define KK_BAR5()                                        \
@@ -465,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
       } else if (a.act == KK_ACT_GELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          v[k].x = gelu_exact5(v[k].x);
-          v[k].y = gelu_exact5(v[k].y);
+          v[k].x = gelu_exact(v[k].x);
+          v[k].y = gelu_exact(v[k].y);
         }
       } else if (NRM == 0 && a.act == KK_ACT_GELU_TANH) {
 #pragma unroll
