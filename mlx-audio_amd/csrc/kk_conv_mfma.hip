@@ -297,6 +297,7 @@ int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t s
   if (a.nrm_a && (a.nrm_stride % 4 != 0 || a.nrm_stride < a.CinP)) return kk_fail("conv_mfma: bad AdaIN parameter pitch");
   const int rows = kk_mfma_tile_rows(a.Q);
   const int nrm = a.nrm_a == nullptr ? 0 : (a.nrm_act == KK_ACT_SNAKE ? 1 : 2);
+  if (nrm == 1 && a.nrm_C % 4 != 0) return kk_fail("conv_mfma: the fused Snake input needs a channel count that is a multiple of 4");
   KKMfmaArgs g = a;
   if (nrm == 2 && a.nrm_act != KK_ACT_LRELU) g.nrm_slope = 1.0f;  // plain AdaIN: identity activation
   if (out_dtype != KK_BF16) {

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
     for (int it = 0; it < nit; ++it) {
       const int chunk = it / ntaps, tap = it - chunk * ntaps;
       const bool last_tap = tap == ntaps - 1;
-      // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land
+      // prefetch the next channel slab of X at the FIRST tap of this slab: it has ntaps iterations to land.  (Measured in round 2: hipcc loads the
+      // slab into rotated registers under this condition and moves them into place behind vmcnt waits, i.e. it waits for the rows here.  A slab loop
+      // with the request outside any condition removes those waits and is 2.5 % SLOWER on the k = 11 layers, +-0 elsewhere: vmcnt retires in order, so
+      // the weight fragments requested after the rows wait for them one tap later anyway, and the second workgroup of the CU covers either stall.)
       if (tap == 0 && chunk + 1 < nchunk) load_x(chunk + 1);
       // next iteration's fragments (the last iteration re-requests its own: no branch around the loads)
       const uint4* fn = frag_ptr(it + 1 < nit ? it + 1 : it);
@@ -283,6 +286,7 @@ int kk_launch_conv_mfma4(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t 
   if (a.Q <= 0 || B <= 0) return 0;
   if (!a.wf) return kk_fail("conv_mfma4: fragment-order weights missing");
   const int nrm = a.nrm_a == nullptr ? 0 : (a.nrm_act == KK_ACT_SNAKE ? 1 : 2);
+  if (nrm == 1 && a.nrm_C % 4 != 0) return kk_fail("conv_mfma: the fused Snake input needs a channel count that is a multiple of 4");
   KKMfmaArgs g = a;
   if (nrm == 2 && a.nrm_act != KK_ACT_LRELU) g.nrm_slope = 1.0f;  // plain AdaIN: identity activation
   if (out_dtype != KK_BF16) return kk_fail("conv_mfma4: bf16 output only");

@@ -4,22 +4,22 @@
 // bit for bit by the `mfma4` test fixture).  Names taken from the including scope: a, b, tid, q0, off0, min_off, xrows, xb, Lin, lin_hi,
 // cin_real, Xs, Ps, XREG, XLD, CK, NRM, bf16_t / bf16x2.  Defines: xreg, preg, xok, load_x(chunk), store_p(chunk), store_x(chunk).
     uint4 xreg[XREG];
-    float4 preg = make_float4(0.f, 0.f, 0.f, 0.f);  // threads 0..47: one float4 of the slab's A | B | alpha
+    float4 preg = make_float4(0.f, 0.f, 0.f, 0.f);  // lanes 0..15 of waves 0 / 1 / 2: one float4 of the slab's A / B / alpha
     unsigned xok = 0;
 
     auto load_x = [&](int chunk) __attribute__((always_inline)) {
       xok = 0;
       // parameter loads go FIRST: vmcnt retires in order, so storing them to LDS one tap later does not wait for the slab
-      if (NRM && tid < 48) {
-        const int which = tid >> 4, c = chunk * CK + (tid & 15) * 4;
-        if (which == 0) preg = *(const float4*)(a.nrm_a + (long long)b * a.nrm_stride + c);
-        else if (which == 1) preg = *(const float4*)(a.nrm_b + (long long)b * a.nrm_stride + c);
-        else if (NRM == 1) {
-          preg.x = (c + 0) < a.nrm_C ? a.nrm_alpha[c + 0] : 1.0f;
-          preg.y = (c + 1) < a.nrm_C ? a.nrm_alpha[c + 1] : 1.0f;
-          preg.z = (c + 2) < a.nrm_C ? a.nrm_alpha[c + 2] : 1.0f;
-          preg.w = (c + 3) < a.nrm_C ? a.nrm_alpha[c + 3] : 1.0f;
-        }
+      // ONE unconditional float4 per thread, its source chosen per WAVE (wave 0: A, 1: B, 2: alpha; lanes 0..15 hold the slab's 64 channels,
+      // the other lanes and wave 3 re-read valid rows and store nothing): a load under `if (which == ...)` is waited for where the paths
+      // merge -- vmcnt(0), i.e. also for the weight fragments in flight, once per slab -- and a per-lane choice of the base pointer becomes a
+      // dependent table load.  Alpha's "1 past the real channels" is applied at store_p; alpha is read in whole float4 groups
+      // (nrm_C % 4 == 0, checked by the launcher).
+      if (NRM) {
+        const int which = __builtin_amdgcn_readfirstlane(tid >> 6), c = chunk * CK + (tid & 15) * 4;
+        const float* base = (NRM == 1 && which == 2) ? a.nrm_alpha : (which == 1 ? a.nrm_b : a.nrm_a) + (long long)b * a.nrm_stride;
+        const int off = (NRM == 1 && which == 2) ? (c + 3 < a.nrm_C ? c : 0) : c;
+        preg = *(const float4*)(base + off);
       }
 #pragma unroll
       for (int i = 0; i < XREG; ++i) {
@@ -35,7 +35,12 @@
       asm volatile("" ::: "memory");
     };
     auto store_p = [&](int chunk) __attribute__((always_inline)) {
-      if (NRM && tid < 48) *(float4*)(Ps + (chunk & 1) * 3 * CK + (tid >> 4) * CK + (tid & 15) * 4) = preg;
+      if (NRM && tid < 192 && (tid & 63) < 16) {
+        const int which = tid >> 6, l = tid & 15;
+        float4 p = preg;
+        if (NRM == 1 && which == 2 && chunk * CK + l * 4 + 3 >= a.nrm_C) p = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // pad channels
+        *(float4*)(Ps + (chunk & 1) * 3 * CK + which * CK + l * 4) = p;
+      }
     };
     auto store_x = [&](int chunk) __attribute__((always_inline)) {
       // value barrier: without it hipcc hoists the first unpack instructions of this function up to the loads in load_x
