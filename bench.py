@@ -198,7 +198,7 @@ def bench_csm(args, rank, world):
 
     def step():
         # the whole job: reference audio -> Mimi.encode -> prompt frames -> prompt block -> FRAMES frames (greedy: deterministic) -> Mimi.decode
-        prompts = [model.prompt_frames(ctx[b], texts[b], 0, voice_match=False) for b in range(B)]
+        prompts = model.prompt_frames_batch(ctx, texts, 0, voice_match=False)  # the B reference clips in one Mimi.encode call
         return model.generate_batch(prompts, max_audio_length_ms=80 * FRAMES, temperature=0.0, stop_on_eos=False), prompts[0][0].shape[0]
 
     def barrier():

@@ -151,10 +151,26 @@ class Model:
     def _tokenize_text_ids(self, ids):  # (round-1 name)
         return self._tokenize_text_segment(list(ids), 0)
 
-    def _tokenize_audio(self, audio: np.ndarray, add_eos: bool = True):
+    def encode_audios(self, audios: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """Mimi codes (K, T) of several clips; clips of equal length go through ONE `Mimi.encode` call (an addition: the reference encodes
+        one clip per call, sesame.py:500-510; a batch item's codes do not depend on its neighbours).  Clips of different lengths are not
+        padded into one call: the encoder transformer sees the whole clip (no mask), so padding would change the codes."""
         if self._audio_tokenizer is None:
             raise ValueError("reference audio needs the Mimi codec: pass mimi= or config['mimi_path']")
-        codes = self._audio_tokenizer.encode(torch.tensor(np.asarray(audio, np.float32))[None, None])[0].cpu().numpy()  # (K, T)
+        out: List[Optional[np.ndarray]] = [None] * len(audios)
+        groups: Dict[int, List[int]] = {}
+        for i, a in enumerate(audios):
+            groups.setdefault(int(np.asarray(a).shape[-1]), []).append(i)
+        for n, idx in groups.items():
+            batch = np.stack([np.asarray(audios[i], np.float32).reshape(n) for i in idx])[:, None, :]
+            codes = self._audio_tokenizer.encode(torch.tensor(batch)).cpu().numpy()  # (len(idx), K, T)
+            for j, i in enumerate(idx):
+                out[i] = codes[j]
+        return out  # type: ignore[return-value]
+
+    def _tokenize_audio(self, audio: np.ndarray, add_eos: bool = True, codes: Optional[np.ndarray] = None):
+        if codes is None:
+            codes = self.encode_audios([audio])[0]  # (K, T)
         if add_eos:
             codes = np.concatenate([codes, np.zeros((codes.shape[0], 1), codes.dtype)], axis=1)
         f = np.zeros((codes.shape[1], self.n_cb + 1), np.int32)
@@ -163,14 +179,22 @@ class Model:
         m[:, :-1] = 1
         return f, m
 
-    def _tokenize_segment(self, seg: Segment, add_eos: bool = True):
+    def _tokenize_segment(self, seg: Segment, add_eos: bool = True, codes: Optional[np.ndarray] = None):
         tf, tm = self._tokenize_text_segment(seg.text, seg.speaker)
         if seg.audio is None:
             return tf, tm
-        af, am = self._tokenize_audio(seg.audio, add_eos=add_eos)
+        af, am = self._tokenize_audio(seg.audio, add_eos=add_eos, codes=codes)
         return np.concatenate([tf, af], 0), np.concatenate([tm, am], 0)
 
-    def prompt_frames(self, context: Sequence[Segment], text: Optional[TextLike], speaker: int = 0, voice_match: bool = False):
+    def prompt_frames_batch(self, contexts: Sequence[Sequence[Segment]], texts: Sequence[Optional[TextLike]], speaker: int = 0, voice_match: bool = False):
+        """`prompt_frames` for several streams with every reference clip of every stream encoded in as few `Mimi.encode` calls as their lengths
+        allow (`encode_audios`); the same prompts, bit for bit, as one `prompt_frames` call per stream."""
+        clips = [seg.audio for ctx in contexts for seg in (ctx[:1] if voice_match else ctx) if seg.audio is not None]
+        codes = {id(a): c for a, c in zip(clips, self.encode_audios(clips))} if clips else {}
+        return [self.prompt_frames(ctx, text, speaker, voice_match, _codes=codes) for ctx, text in zip(contexts, texts)]
+
+    def prompt_frames(self, context: Sequence[Segment], text: Optional[TextLike], speaker: int = 0, voice_match: bool = False,
+                      _codes: Optional[Dict[int, np.ndarray]] = None):
         """The prompt of one stream as (tokens [S, n_cb+1] int32, mask [S, n_cb+1] float32) -- sesame.py:727-757.
         voice_match (the reference's default): ONE segment whose text is `context[0].text + " " + text` and whose audio is the context's,
         without an EOS frame (the model continues the speaker's audio).  Otherwise: every context segment (with EOS frames), then the text."""
@@ -184,10 +208,11 @@ class Model:
                 joined = list(self._text_ids(c0.text, speaker)) + list(self._text_ids(text, speaker))
             else:
                 joined = (c0.text + " " + text).strip()
-            return self._tokenize_segment(Segment(speaker=speaker, text=joined, audio=c0.audio), add_eos=False)
+            return self._tokenize_segment(Segment(speaker=speaker, text=joined, audio=c0.audio), add_eos=False,
+                                          codes=(_codes or {}).get(id(c0.audio)))
         ft, fm = [], []
         for seg in context:
-            a, b = self._tokenize_segment(seg, add_eos=True)
+            a, b = self._tokenize_segment(seg, add_eos=True, codes=(_codes or {}).get(id(seg.audio)))
             ft.append(a)
             fm.append(b)
         if text is not None:

@@ -348,6 +348,19 @@ def test_csm_model_generate_surface_voice_match_and_stream():
     parts = list(loop.generate(prompts[0], ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, temperature=0.0, stop_on_eos=False,
                                stream=True, streaming_interval=0.16))
     assert [p.token_count for p in parts] == [2, 2, 1] and sum(p.samples for p in parts) == res[0].samples
+    # prompt_frames_batch: every stream's reference clips through as few Mimi.encode calls as their lengths allow -> the same prompts, bit for bit
+    from mlx_audio_amd.sesame import Segment
+
+    ref2 = (0.3 * rng.standard_normal(1920 * 3)).astype(np.float32)
+    ref3 = (0.3 * rng.standard_normal(1920 * 2)).astype(np.float32)
+    ctxs = [[Segment(0, ref_ids, ref)], [Segment(0, ref_ids, ref2), Segment(1, prompts[1], ref3)], [Segment(0, ref_ids, None)]]
+    for vm in (False, True):
+        use = ctxs[:2] if vm else ctxs
+        got = loop.prompt_frames_batch(use, [prompts[0]] * len(use), 0, voice_match=vm)
+        for c, (gf, gm) in zip(use, got):
+            wf, wm = loop.prompt_frames(c, prompts[0], 0, voice_match=vm)
+            np.testing.assert_array_equal(gf, wf)
+            np.testing.assert_array_equal(gm, wm)
 
 
 def test_load_model_routes_sesame_checkpoints(tmp_path):
