@@ -275,6 +275,69 @@ __global__ __launch_bounds__(256) void rvq_argmin_kernel(const float* dots, cons
   for (int c = tid; c < qdim; c += 256) r[c] -= cb[(long long)idx * qdim + c];
 }
 
+
+// ---- nn.Linear on a FEW rows (the streaming steps: 2 rows per item and frame): the work is reading W [K][N] once.  The generic conv tile
+// (64 rows x 64 columns per workgroup) runs a 2-row linear at ~100 us; here a workgroup owns 16 output columns, its 256 threads are
+// 16 columns x 16 k-slices, a thread walks its slice of K with LR_U loads in flight and keeps MT row accumulators; the 16 slices meet in LDS
+// in slice order (fixed: a row's bits do not depend on its batch neighbours or on MT).  Epilogue as conv_generic_kernel's: bias, tanh-GELU,
+// + residual, + old output.  x row m at x + (m / rows) * xbs + (m % rows) * ldx.
+constexpr int LR_COLS = 16, LR_SL = 16, LR_U = 8;
+struct LinRowsArgs {
+  const float* x; long long xbs; int ldx, rows;
+  const float* w; int ldw;
+  const float* bias;
+  const float* res; long long rbs; int ldr;
+  float* out; long long obs; int ldo;
+  int K, N, M, act, accumulate;
+};
+template <int MT>
+__global__ __launch_bounds__(256) void linear_rows_kernel(LinRowsArgs a) {
+  __shared__ float red[LR_SL][MT][LR_COLS + 1];
+  const int tid = threadIdx.x, col = tid & (LR_COLS - 1), sl = tid >> 4;
+  const int n = blockIdx.x * LR_COLS + col, m0 = blockIdx.y * MT;
+  const int nc = n < a.N ? n : a.N - 1;
+  const int kper = (a.K + LR_SL - 1) / LR_SL, k0 = sl * kper, k1 = min(a.K, k0 + kper);
+  const float* xr[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mm = m0 + m < a.M ? m0 + m : a.M - 1;
+    xr[m] = a.x + (long long)(mm / a.rows) * a.xbs + (long long)(mm % a.rows) * a.ldx;
+  }
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (int k = k0; k < k1; k += LR_U) {
+    float wv[LR_U];
+#pragma unroll
+    for (int u = 0; u < LR_U; ++u) wv[u] = a.w[(long long)(k + u < k1 ? k + u : k1 - 1) * a.ldw + nc];  // (clamped: no load under a condition)
+#pragma unroll
+    for (int u = 0; u < LR_U; ++u) {
+      const float live = k + u < k1 ? 1.0f : 0.0f;
+      const int kk = k + u < k1 ? k + u : k1 - 1;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_fmaf(xr[m][kk] * live, wv[u], acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) red[sl][m][col] = acc[m];
+  __syncthreads();
+  for (int o = tid; o < MT * LR_COLS; o += 256) {
+    const int m = o / LR_COLS, c = o - m * LR_COLS;
+    const int mg = m0 + m, ng = blockIdx.x * LR_COLS + c;
+    if (mg >= a.M || ng >= a.N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < LR_SL; ++s2) v += red[s2][m][c];  // slice order
+    v += a.bias ? a.bias[ng] : 0.f;
+    if (a.act == KK_ACT_GELU_TANH) v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));  // nn.gelu_approx
+    const long long b = mg / a.rows, r = mg % a.rows;
+    if (a.res) v += a.res[b * a.rbs + r * a.ldr + ng];
+    float* o_ = a.out + b * a.obs + r * a.ldo + ng;
+    if (a.accumulate) v += *o_;
+    *o_ = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 uint16_t f32_to_bf16_rne(float f) {
@@ -383,6 +446,7 @@ struct Run {
   bool dry;
   bool oom = false;
   int adt = -1;  // activation dtype of this run (-1: the model's)
+  bool no_lin_rows = false;  // (A/B: the generic conv kernel for the few-row linears too)
   void* raw(size_t bytes) {
     const size_t off = (used + 255) & ~(size_t)255;
     used = off + bytes;
@@ -416,6 +480,23 @@ struct Run {
       g.lin = KKLen{nullptr, 0, Lin}; g.lout = KKLen{nullptr, 0, Lout};
       g.in_slope = 1.f; g.scale = 1.f; g.accumulate = accumulate; g.act = act_; g.in_act = in_act;
       return kk_launch_conv_mfma4(g, B, KK_BF16, st);
+    }
+    // a linear over a few rows (the streaming steps): weight-streaming kernel instead of the 64-row conv tile
+    if (w.K == 1 && !transposed && stride == 1 && pad == 0 && in_act == 0 && x.dtype == KK_F32 && out.dtype == KK_F32 && x.rows == out.rows &&
+        x.rows <= 8 && (act_ == KK_ACT_NONE || act_ == KK_ACT_GELU_TANH) && w.Cout >= 64 && !no_lin_rows) {  // (by rows per item, never by B: batch invariance)
+      LinRowsArgs g;
+      memset(&g, 0, sizeof g);
+      g.x = (const float*)x.p; g.xbs = x.bs(); g.ldx = x.ld; g.rows = x.rows;
+      g.w = w.w; g.ldw = w.ldw; g.bias = w.b;
+      if (res) { g.res = (const float*)res->p; g.rbs = res->bs(); g.ldr = res->ld; }
+      g.out = (float*)out.p; g.obs = out.bs(); g.ldo = out.ld;
+      g.K = w.Cin; g.N = w.Cout; g.M = B * x.rows; g.act = act_; g.accumulate = accumulate;
+      const int M = g.M;
+      if (M <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 4)), dim3(256), 0, st, g);
+      else if (M <= 8) hipLaunchKernelGGL(linear_rows_kernel<8>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 8)), dim3(256), 0, st, g);
+      else hipLaunchKernelGGL(linear_rows_kernel<16>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 16)), dim3(256), 0, st, g);
+      KK_CHECK_LAUNCH();
+      return 0;
     }
     KKConvArgs a;
     memset(&a, 0, sizeof a);
