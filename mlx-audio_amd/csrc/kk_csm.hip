@@ -372,7 +372,7 @@ template <int NPER>
 __global__ __launch_bounds__(256) void sample_select_kernel(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out,
                                                             int ostride) {
   __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_krem, ccount;
+  __shared__ unsigned s_prefix, s_krem, s_bin, ccount;
   __shared__ unsigned ckey[64];
   __shared__ int cidx[64];
   __shared__ float topv[64], ev[64];
@@ -386,6 +386,29 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* logits,
   }
   const bool greedy = u == nullptr || temp == 0.f;
   const int k = greedy ? 1 : (top_k < 64 ? (top_k < V ? top_k : V) : 64);
+  if (greedy) {  // arg-max (lower index on ties): the key order is the float order, so one max over (key, ~index) does it -- no histogram
+    __shared__ unsigned long long wbest[4];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+      const int j = tid + 256 * i;
+      const unsigned long long c = j < V ? (((unsigned long long)key[i] << 32) | (unsigned)(0x7fffffff - j)) : 0ull;
+      best = c > best ? c : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(best, o);
+      best = t > best ? t : best;
+    }
+    if (lane == 0) wbest[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long g = wbest[0];
+      for (int w = 1; w < 4; ++w) g = wbest[w] > g ? wbest[w] : g;
+      out[(long long)b * ostride] = 0x7fffffff - (int)(unsigned)(g & 0xffffffffull);
+    }
+    return;
+  }
   unsigned prefix = 0u, mask = 0u, krem = (unsigned)k;
   for (int shift = 24; shift >= 0; shift -= 8) {
     hist[tid] = 0u;
@@ -413,12 +436,16 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* logits,
         else { bin = 252 - 4 * lane; above = exc + c0 + c1 + c2; }
         s_prefix = prefix | (bin << shift);
         s_krem = krem - above;
+        s_bin = hist[bin];
       }
     }
     __syncthreads();
     prefix = s_prefix;
     krem = s_krem;
     mask |= 255u << shift;
+    // every key >= prefix (lower digits zero) is a candidate: the k - krem keys above the chosen digit and the s_bin keys that share it.  Once
+    // they fit the 64-entry sort the remaining digits need not be resolved (typically after two passes: 16 bits separate the top-50 of 2051 logits)
+    if ((unsigned)k - krem + s_bin <= 64u) break;
   }
   if (tid == 0) ccount = 0u;
   __syncthreads();

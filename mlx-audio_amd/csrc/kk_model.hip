@@ -1327,8 +1327,9 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     c.st_rstd = c.f32(cmax);
     // fused-norm scratch of the bf16 MFMA path
     c.fz_stride = rup(std::max(std::max(DH + 2 + 64, H + S), C0), 64);
-    const size_t tiles = std::max(std::max((size_t)kk_cdiv(Tf, 128) * (C0 / 4), (size_t)kk_cdiv(L20, 128) * (C0 / 2)),
-                                  (size_t)kk_cdiv(L2, 128) * std::max(DH, H));
+    // (+ 16 tiles: a polyphase transposed conv has ceil(Q / rows) tiles PER PHASE, up to stride - 1 more than ceil(L / rows) in total)
+    const size_t tiles = std::max(std::max((size_t)(kk_cdiv(Tf, 128) + 16) * (C0 / 4), (size_t)(kk_cdiv(L20, 128) + 16) * (C0 / 2)),
+                                  (size_t)(kk_cdiv(L2, 128) + 16) * std::max(DH, H));
     c.fz_part_floats = (size_t)B * tiles * 2;
     float* fp = c.f32(c.fz_part_floats);
     float* p0 = c.f32((size_t)B * c.fz_stride);
