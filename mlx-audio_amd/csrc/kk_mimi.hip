@@ -276,40 +276,56 @@ __global__ __launch_bounds__(256) void rvq_argmin_kernel(const float* dots, cons
 }
 
 
-// ---- nn.Linear on a FEW rows (the streaming steps: 2 rows per item and frame): the work is reading W [K][N] once.  The generic conv tile
-// (64 rows x 64 columns per workgroup) runs a 2-row linear at ~100 us; here a workgroup owns 16 output columns, its 256 threads are
-// 16 columns x 16 k-slices, a thread walks its slice of K with LR_U loads in flight and keeps MT row accumulators; the 16 slices meet in LDS
-// in slice order (fixed: a row's bits do not depend on its batch neighbours or on MT).  Epilogue as conv_generic_kernel's: bias, tanh-GELU,
-// + residual, + old output.  x row m at x + (m / rows) * xbs + (m % rows) * ldx.
+// ---- linears and convolutions over a FEW rows (the streaming steps: 2 rows per item and frame): the work is reading W once.  The generic
+// conv tile (64 rows x 64 columns per workgroup) runs a 2-row linear at ~100 us and the first SEANet layers (k 7 512 -> 1024 on 2 + 6 rows,
+// transposed k 16 1024 -> 512 on 1 + 2 rows: 15 / 34 MB of weights) at 320-360 us.  Here a workgroup owns 16 output columns, its 256 threads
+// are 16 columns x 16 k-slices, a thread walks its slice of K' with LR_U loads in flight and keeps MT row accumulators; the 16 slices meet in
+// LDS in slice order (fixed: a row's bits do not depend on its batch neighbours or on MT).  Three forms share the loop:
+//   * linear:                      K' = Cin;            row m = (item, r) reads x row r;
+//   * causal conv, stride 1, pad 0 over rows with pitch == Cin: the k taps of output row r are the CONTIGUOUS window x[r .. r + k - 1], so
+//     it is a linear with K' = k * Cin on the flattened window and W [k][Cin][N] read as [K'][N];
+//   * transposed conv with k = 2 * stride (polyphase, blockIdx.z = phase p): output row p + s * q = W[p] x[q] + W[p + s] x[q - 1], a linear
+//     with K' = 2 * Cin over the window x[q - 1 .. q] whose first half meets weight rows (p + s) * Cin .. and second half p * Cin ..;
+//     q runs from 1 (row 0 of x is the carried previous input row; output rows [0, s) are not written).
+// An ELU on the input is applied by a pre-pass into scratch (Run::elu_tmp): inside the loop every element would be transformed by 16 lanes
+// of every workgroup.  Epilogue as conv_generic_kernel's: bias, tanh-GELU, + residual, + old output.
 constexpr int LR_COLS = 16, LR_SL = 16, LR_U = 8;
+constexpr int LR_MAX_ROWS = 128;  // output rows per item up to which the few-rows kernel is used (beyond: the tiled generic kernel)
 struct LinRowsArgs {
-  const float* x; long long xbs; int ldx, rows;
+  const float* x; long long xbs; int ldx, rows;   // rows: output rows per item (per phase for the transposed form)
   const float* w; int ldw;
   const float* bias;
   const float* res; long long rbs; int ldr;
   float* out; long long obs; int ldo;
   int K, N, M, act, accumulate;
+  int Cin, tstride;  // tstride > 0: transposed form with that stride
 };
 template <int MT>
 __global__ __launch_bounds__(256) void linear_rows_kernel(LinRowsArgs a) {
   __shared__ float red[LR_SL][MT][LR_COLS + 1];
   const int tid = threadIdx.x, col = tid & (LR_COLS - 1), sl = tid >> 4;
-  const int n = blockIdx.x * LR_COLS + col, m0 = blockIdx.y * MT;
+  const int n = blockIdx.x * LR_COLS + col, m0 = blockIdx.y * MT, phase = blockIdx.z;
   const int nc = n < a.N ? n : a.N - 1;
   const int kper = (a.K + LR_SL - 1) / LR_SL, k0 = sl * kper, k1 = min(a.K, k0 + kper);
   const float* xr[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int mm = m0 + m < a.M ? m0 + m : a.M - 1;
-    xr[m] = a.x + (long long)(mm / a.rows) * a.xbs + (long long)(mm % a.rows) * a.ldx;
+    xr[m] = a.x + (long long)(mm / a.rows) * a.xbs + (long long)(mm % a.rows) * a.ldx;  // (transposed: window rows q - 1, q with q = mm % rows + 1)
   }
+  // weight row of flattened index k: identity, or the two taps of this phase
+  const int wr0 = a.tstride ? (phase + a.tstride) * a.Cin : 0, wr1 = a.tstride ? phase * a.Cin - a.Cin : 0;
   float acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
   for (int k = k0; k < k1; k += LR_U) {
     float wv[LR_U];
 #pragma unroll
-    for (int u = 0; u < LR_U; ++u) wv[u] = a.w[(long long)(k + u < k1 ? k + u : k1 - 1) * a.ldw + nc];  // (clamped: no load under a condition)
+    for (int u = 0; u < LR_U; ++u) {
+      const int kk = k + u < k1 ? k + u : k1 - 1;  // (clamped: no load under a condition)
+      const int wrow = a.tstride ? (kk < a.Cin ? wr0 + kk : wr1 + kk) : kk;
+      wv[u] = a.w[(long long)wrow * a.ldw + nc];
+    }
 #pragma unroll
     for (int u = 0; u < LR_U; ++u) {
       const float live = k + u < k1 ? 1.0f : 0.0f;
@@ -330,12 +346,20 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinRowsArgs a) {
     for (int s2 = 0; s2 < LR_SL; ++s2) v += red[s2][m][c];  // slice order
     v += a.bias ? a.bias[ng] : 0.f;
     if (a.act == KK_ACT_GELU_TANH) v = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));  // nn.gelu_approx
-    const long long b = mg / a.rows, r = mg % a.rows;
+    const long long b = mg / a.rows;
+    const long long r = a.tstride ? phase + (long long)a.tstride * (mg % a.rows + 1) : mg % a.rows;
     if (a.res) v += a.res[b * a.rbs + r * a.ldr + ng];
     float* o_ = a.out + b * a.obs + r * a.ldo + ng;
     if (a.accumulate) v += *o_;
     *o_ = v;
   }
+}
+// nn.elu of [B][rows][C] (pitch C) into dense scratch: the pre-pass of the few-rows kernel
+__global__ __launch_bounds__(256) void elu_rows_kernel(const float* x, long long xbs, long long n, float* out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float v = x[(long long)blockIdx.y * xbs + e];
+  out[(long long)blockIdx.y * n + e] = v > 0.f ? v : expf(v) - 1.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------------- host
@@ -446,7 +470,9 @@ struct Run {
   bool dry;
   bool oom = false;
   int adt = -1;  // activation dtype of this run (-1: the model's)
-  bool no_lin_rows = false;  // (A/B: the generic conv kernel for the few-row linears too)
+  bool no_lin_rows = false;  // (A/B: the generic conv kernel for the few-row layers too)
+  float* elu_tmp = nullptr;  // dense scratch for an ELU'd input of the few-rows kernel (streaming steps allocate it)
+  size_t elu_floats = 0;
   void* raw(size_t bytes) {
     const size_t off = (used + 255) & ~(size_t)255;
     used = off + bytes;
@@ -481,22 +507,38 @@ struct Run {
       g.in_slope = 1.f; g.scale = 1.f; g.accumulate = accumulate; g.act = act_; g.in_act = in_act;
       return kk_launch_conv_mfma4(g, B, KK_BF16, st);
     }
-    // a linear over a few rows (the streaming steps): weight-streaming kernel instead of the 64-row conv tile
-    if (w.K == 1 && !transposed && stride == 1 && pad == 0 && in_act == 0 && x.dtype == KK_F32 && out.dtype == KK_F32 && x.rows == out.rows &&
-        x.rows <= 8 && (act_ == KK_ACT_NONE || act_ == KK_ACT_GELU_TANH) && w.Cout >= 64 && !no_lin_rows) {  // (by rows per item, never by B: batch invariance)
-      LinRowsArgs g;
-      memset(&g, 0, sizeof g);
-      g.x = (const float*)x.p; g.xbs = x.bs(); g.ldx = x.ld; g.rows = x.rows;
-      g.w = w.w; g.ldw = w.ldw; g.bias = w.b;
-      if (res) { g.res = (const float*)res->p; g.rbs = res->bs(); g.ldr = res->ld; }
-      g.out = (float*)out.p; g.obs = out.bs(); g.ldo = out.ld;
-      g.K = w.Cin; g.N = w.Cout; g.M = B * x.rows; g.act = act_; g.accumulate = accumulate;
-      const int M = g.M;
-      if (M <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 4)), dim3(256), 0, st, g);
-      else if (M <= 8) hipLaunchKernelGGL(linear_rows_kernel<8>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 8)), dim3(256), 0, st, g);
-      else hipLaunchKernelGGL(linear_rows_kernel<16>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 16)), dim3(256), 0, st, g);
-      KK_CHECK_LAUNCH();
-      return 0;
+    // few rows per item (the streaming steps): the weight-streaming kernel instead of the 64-row conv tile.  Chosen by the rows per ITEM,
+    // never by B (batch invariance).  Forms: linear; causal conv over contiguous rows (pad 0, stride 1, pitch == Cin); transposed conv k = 2 s.
+    {
+      const bool f32io = x.dtype == KK_F32 && out.dtype == KK_F32 && dil == 1 && pad == 0 && w.Cout >= 32 && !no_lin_rows &&
+                         (act_ == KK_ACT_NONE || act_ == KK_ACT_GELU_TANH) && (in_act == 0 || (in_act == KK_ACT_ELU && elu_tmp));
+      const bool lin = f32io && !transposed && stride == 1 && x.ld == w.Cin && x.rows == out.rows + w.K - 1 && out.rows <= LR_MAX_ROWS;
+      const bool ctr = f32io && transposed && w.K == 2 * stride && x.ld == w.Cin && out.rows == x.rows * stride && x.rows >= 2 &&
+                       x.rows - 1 <= LR_MAX_ROWS && !res && !accumulate;
+      if (lin || ctr) {
+        LinRowsArgs g;
+        memset(&g, 0, sizeof g);
+        g.x = (const float*)x.p; g.xbs = x.bs(); g.ldx = x.ld;
+        if (in_act == KK_ACT_ELU) {  // ELU once, into dense scratch
+          const long long n = (long long)x.rows * x.ld;
+          if ((size_t)B * n > elu_floats) return kk_fail("kk_mimi: internal: ELU scratch too small");
+          hipLaunchKernelGGL(elu_rows_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, (const float*)x.p, x.bs(), n, elu_tmp);
+          KK_CHECK_LAUNCH();
+          g.x = elu_tmp; g.xbs = n;
+        }
+        g.rows = ctr ? x.rows - 1 : out.rows;
+        g.w = w.w; g.ldw = w.ldw; g.bias = w.b;
+        if (res) { g.res = (const float*)res->p; g.rbs = res->bs(); g.ldr = res->ld; }
+        g.out = (float*)out.p; g.obs = out.bs(); g.ldo = out.ld;
+        g.Cin = w.Cin; g.tstride = ctr ? stride : 0;
+        g.K = ctr ? 2 * w.Cin : w.K * w.Cin; g.N = w.Cout; g.M = B * g.rows; g.act = act_; g.accumulate = accumulate;
+        const int M = g.M, nz = ctr ? stride : 1;
+        if (M <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 4), nz), dim3(256), 0, st, g);
+        else if (M <= 8) hipLaunchKernelGGL(linear_rows_kernel<8>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 8), nz), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(linear_rows_kernel<16>, dim3(kk_cdiv(g.N, LR_COLS), kk_cdiv(M, 16), nz), dim3(256), 0, st, g);
+        KK_CHECK_LAUNCH();
+        return 0;
+      }
     }
     KKConvArgs a;
     memset(&a, 0, sizeof a);
@@ -799,12 +841,25 @@ int stream_begin(Run& r, kk_mimi_stream* s) {  // zero state on the first step a
   return 0;
 }
 
+// dense scratch for the ELU'd input of the few-rows kernel: the largest [S + n][C] block among the stream's state buffers (and the
+// residual blocks' hidden rows, which are never wider than their input)
+void stream_elu_scratch(Run& r, kk_mimi_stream* s) {
+  size_t mx = 0;
+  auto upd = [&](const StateBuf& b) { mx = std::max(mx, (size_t)(b.S + b.n) * b.C); };
+  upd(s->first); upd(s->last); upd(s->resample);
+  for (const auto& b : s->up) upd(b);
+  for (const auto& b : s->blk) upd(b);
+  r.elu_floats = (size_t)r.B * mx;
+  r.elu_tmp = (float*)r.raw(r.elu_floats * 4);
+}
+
 int run_decode_step(Run& r, kk_mimi_stream* s, const int* codes, float* pcm_out) {
   kk_mimi* m = r.m;
   const kk_mimi_config& c = m->cfg;
   const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, F = s->chunk;
   Act q1 = r.act(F, Q), q2 = r.act(F, Q), xu = r.act((F + 1) * us, D), x = r.act(F * us, D), xup = r.act(F * us, D);
   Act n = r.act(F * us, D), qkv = r.act(F * us, 3 * D), att = r.act(F * us, D), hbuf = r.act(F * us, c.dim_feedforward);
+  stream_elu_scratch(r, s);
   if (r.oom) return kk_fail("kk_mimi_decode_step: workspace too small");
   if (!r.dry && s->pos + F * us > s->max_pos) return kk_fail("kk_mimi_decode_step: the stream is longer than max_frames (kk_mimi_stream_create)");
   MM_TRY(stream_begin(r, s));
@@ -869,6 +924,8 @@ int run_encode_step(Run& r, kk_mimi_stream* s, const float* pcm, int* codes) {
   const int B = r.B, D = c.dim, Q = c.qdim, us = c.upsample_stride, F = s->chunk, T = F * us;
   const int N = s->first.n;
   if (!r.dry && s->pos + T > s->max_pos) return kk_fail("kk_mimi_encode_step: the stream is longer than max_frames (kk_mimi_encode_stream_create)");
+  stream_elu_scratch(r, s);
+  if (r.oom) return kk_fail("kk_mimi_encode_step: workspace too small");
   MM_TRY(stream_begin(r, s));
   Act in;
   in.p = const_cast<float*>(pcm); in.rows = N; in.C = 1; in.ld = 1; in.dtype = KK_F32;
