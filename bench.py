@@ -122,6 +122,10 @@ def main():
                     help="with --quantized: 'exact' (default) = the dequantised weights scale*q+bias on the bf16 MFMA kernels, the reference's arithmetic "
                          "(tts/utils.py:241-260); 'mxfp8' = the opt-in e4m3 kernels.  The other one is measured too and reported next to `value`.")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight (kokoro): consecutive steps alternate over this many HIP streams, each with its own engine instance, "
+                         "workspace and captured graph, so the latency-bound text / LSTM phases of step i+1 overlap the conv-bound generator of step i "
+                         "(1 = strictly one step after the other)")
     ap.add_argument("--config", default="kokoro", choices=["kokoro", "csm"],
                     help="kokoro (default): BASELINE configs[1], the headline.  csm: configs[3], CSM-1B + Mimi at the SURVEY 8(d) pin -- B = 8 streams, each a "
                          "10 s reference-audio prompt (125 Mimi frames) + 64 text ids, 125 frames generated greedily, Mimi decode included; a step is one "
@@ -329,7 +333,9 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         w = {k: torch.tensor(np.asarray(v, np.float32)).to(torch.bfloat16) for k, v in w.items()}  # an 8-bit checkpoint of the bf16 model
     if args.dtype == "bfloat16" and not args.quantized:
         w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
-    eng = KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization)
+    NS = max(1, int(args.streams))
+    engs = [KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization) for _ in range(NS)]  # same weights; own workspace + graph each
+    eng = engs[0]
     if args.quantized:
         assert eng.lib.kk_quantized_layers(eng._h) == (6 if quantization_kernel == "mxfp8" else 0)
     dev = eng.device
@@ -350,20 +356,25 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
     Fmax = FRAMES_PER_TOKEN * Tmax
     # two waveform buffers: with N > 1 the gather of batch i (the path's one exchange step: every shard's waveforms land on rank 0)
     # runs on RCCL's stream while batch i+1 is synthesised into the other buffer
-    nbuf = 2 if world > 1 else 1
+    nbuf = max(NS, 2 if world > 1 else 1)
     wavs = [torch.empty((B, 600 * Fmax), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     gathered = [torch.empty((Bglob, 600 * Fmax), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None for _ in range(nbuf)]
     pending = [None] * nbuf
-    eng.workspace(B, Tmax, Fmax)
+    for e in engs:
+        e.workspace(B, Tmax, Fmax)
+    # NS batches in flight: step i runs on stream i % NS with engine i % NS (its own workspace and captured graph) into waveform buffer i % nbuf
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(NS - 1)]
 
-    def step(i):
+    def step(i, single=False):
         j = i % nbuf
-        if pending[j] is not None:
-            pending[j].wait()  # batch i-2 has left this buffer
-            pending[j] = None
-        eng.forward(ids, lens, ref_s, speed, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=1000 + i, out=wavs[j])
-        if world > 1:
-            pending[j] = gather_waveforms(wavs[j], gathered[j], dist, async_op=True)
+        k = 0 if single else i % NS
+        with torch.cuda.stream(streams[k]):
+            if pending[j] is not None:
+                pending[j].wait()  # the batch that used this buffer last has left it
+                pending[j] = None
+            engs[k].forward(ids, lens, ref_s, speed, Fmax, forced_dur=forced, noise_mode=_lib.NOISE_PHILOX, seed=1000 + i, out=wavs[j])
+            if world > 1:
+                pending[j] = gather_waveforms(wavs[j], gathered[j], dist, async_op=True)
 
     def drain():
         for j in range(nbuf):
@@ -382,8 +393,9 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
     # roofline figures come from a SECOND, separately timed pass of the same K steps (its wall time is reported too).
     use_graph = not args.no_graph
     if use_graph:
-        eng.set_graph_mode(True)
-    nwarm = max(args.warmup, 2 * nbuf) if use_graph else args.warmup  # eager run + capture per output buffer happen before the clock starts
+        for e in engs:
+            e.set_graph_mode(True)
+    nwarm = max(args.warmup, 2 * nbuf) if use_graph else args.warmup  # eager run + capture per engine / output buffer happen before the clock starts
     for i in range(nwarm):
         step(i)
     barrier()
@@ -392,13 +404,23 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         step(nwarm + i)
     barrier()
     dt = time.perf_counter() - t0
+    dt_one = None
+    if NS > 1 and not brief:  # the same K steps strictly one after the other (engine 0, one stream), for reference
+        for i in range(2 * nbuf):
+            step(i, single=True)  # (engine 0 captures its graph for every output buffer)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, single=True)
+        barrier()
+        dt_one = time.perf_counter() - t1
     prof, dt_prof = None, None
     if not args.no_profile and not brief:
         eng.profile_begin()  # forwards with an open profile run eagerly
         barrier()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            step(nwarm + args.steps + i)
+            step(nwarm + args.steps + i, single=True)
         barrier()
         dt_prof = time.perf_counter() - t1
         prof = eng.profile_end()
@@ -440,9 +462,12 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         "data": "synthetic (seeded random-init checkpoint of the Kokoro-82M architecture, random phoneme ids, real af_heart style rows, Philox noise)",
         "config": {"workload": f"Kokoro-82M {dtype_tag}, batch={B}/GPU fixed {N_PHONEMES}-phoneme utterances (T={Tmax}, F={Fmax}, {600 * Fmax} samples = "
                                f"{600 * Fmax / SR:.2f} s each), utterance-sharded over {world} GPU(s)" + (" + RCCL gather to rank 0" if world > 1 else ""),
-                   "global_batch": Bglob, "parallelism": f"utterance-shard x{world}"},
+                   "global_batch": Bglob, "parallelism": f"utterance-shard x{world}" + (f", {NS} batches in flight per GPU" if NS > 1 else "")},
     }
     if rank == 0:
+        out["batches_in_flight"] = NS
+        if dt_one is not None:
+            out["ms_per_step_one_batch_in_flight"] = dt_one / args.steps * 1e3  # the same K steps strictly one after the other
         if p50_ms is not None:
             out["p50_latency_ms_b1"] = p50_ms
             out["p50_latency_note"] = "one 128-phoneme utterance (16.25 s audio), kk_forward + sync, median of 10 after 2 warm-ups"
@@ -481,14 +506,14 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
                     tr = pmc["istft_head"]["fetch_corrected_bytes_per_launch"] + pmc["istft_head"]["write_bytes_per_launch"]
                 out["roofline_istft_head"] = {"bound": "hbm", "kernel": "conv_post_istft (conv_post + iSTFT + overlap-add fused; stand-alone iSTFT head in fp32 mode)", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                                               "traffic": tr, "us_per_launch": ih["ms"] / ih["launches"] * 1e3}
-            out["launch_mode"] = "hipGraph replay" if use_graph else "eager"
+            out["launch_mode"] = ("hipGraph replay" if use_graph else "eager") + (f", {NS} batches in flight on {NS} HIP streams" if NS > 1 else "")
             out["ms_per_step_eager_profiled_pass"] = dt_prof / args.steps * 1e3
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
             out["kernel_ms_per_step"]["_sum_bracketed"] = round(tot / args.steps, 3)
         if world == 1 and not args.no_cpu_baseline and not brief:
             out["cpu_baseline"] = cpu_baseline(cfg, P.synth_checkpoint(cfg, 0), utts[0], ref_np[0:1])
-    del eng
+    del eng, engs
     torch.cuda.empty_cache()
     return out
 
