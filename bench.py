@@ -122,10 +122,11 @@ def main():
                     help="with --quantized: 'exact' (default) = the dequantised weights scale*q+bias on the bf16 MFMA kernels, the reference's arithmetic "
                          "(tts/utils.py:241-260); 'mxfp8' = the opt-in e4m3 kernels.  The other one is measured too and reported next to `value`.")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the forward eagerly (default: hipGraph replay, kk_set_graph_mode)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight (kokoro): consecutive steps alternate over this many HIP streams, each with its own engine instance, "
                          "workspace and captured graph, so the latency-bound text / LSTM phases of step i+1 overlap the conv-bound generator of step i "
-                         "(1 = strictly one step after the other)")
+                         "(1 = strictly one step after the other; default 2).  csm: whole B-stream jobs in flight, each on its own stream, host thread "
+                         "and model instance (default 4)")
     ap.add_argument("--config", default="kokoro", choices=["kokoro", "csm"],
                     help="kokoro (default): BASELINE configs[1], the headline.  csm: configs[3], CSM-1B + Mimi at the SURVEY 8(d) pin -- B = 8 streams, each a "
                          "10 s reference-audio prompt (125 Mimi frames) + 64 text ids, 125 frames generated greedily, Mimi decode included; a step is one "
@@ -191,33 +192,77 @@ def bench_csm(args, rank, world):
     w = P.csm_synth_checkpoint(cfg, 0)
     mcfg = P.mimi_config(32)
     mw = P.mimi_synth_checkpoint(mcfg, 0, encode=True)
-    mimi = Mimi(mimi_202407(32), mw, compute_dtype="bfloat16")
-    model = Model(cfg, mimi=mimi, weights=w, weight_dtype="bfloat16")  # a bf16 checkpoint: matrices stored / streamed as bf16, fp32 arithmetic
+    # NS jobs in flight (--streams, default 2): each job is one whole B-stream batch (prompt encode -> prompt block -> FRAMES frames -> decode) on
+    # its own HIP stream, host thread and model instance (own KV caches and graphs).  A frame is ~900 launches of a few microseconds each, so one
+    # job leaves most of the chip idle; two interleave.  The K timed steps are dealt to the jobs from one queue.
+    NS = max(1, int(args.streams if args.streams is not None else 4))
+    models = []
+    for _ in range(NS):
+        mimi = Mimi(mimi_202407(32), mw, compute_dtype="bfloat16")
+        models.append(Model(cfg, mimi=mimi, weights=w, weight_dtype="bfloat16"))  # a bf16 checkpoint: matrices stored / streamed as bf16, fp32 arithmetic
+    model = models[0]
     rng = np.random.default_rng(1000 + rank)
     ctx, texts = [], []
     for b in range(B):
         ref = (0.1 * rng.standard_normal(int(24000 * REF_S))).astype(np.float32)
         ctx.append([Segment(speaker=0, text=rng.integers(0, cfg["text_vocab_size"], N_TEXT // 2).tolist(), audio=ref)])
         texts.append(rng.integers(0, cfg["text_vocab_size"], N_TEXT // 2).tolist())
+    dev = model.model.device
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(NS - 1)]
 
-    def step():
+    def step(k=0):
         # the whole job: reference audio -> Mimi.encode -> prompt frames -> prompt block -> FRAMES frames (greedy: deterministic) -> Mimi.decode
-        prompts = model.prompt_frames_batch(ctx, texts, 0, voice_match=False)  # the B reference clips in one Mimi.encode call
-        return model.generate_batch(prompts, max_audio_length_ms=80 * FRAMES, temperature=0.0, stop_on_eos=False), prompts[0][0].shape[0]
+        prompts = models[k].prompt_frames_batch(ctx, texts, 0, voice_match=False)  # the B reference clips in one Mimi.encode call
+        return models[k].generate_batch(prompts, max_audio_length_ms=80 * FRAMES, temperature=0.0, stop_on_eos=False), prompts[0][0].shape[0]
+
+    def run_steps(n, jobs):
+        """n steps over `jobs` jobs in flight (threads pull step numbers from one counter; a thread's launches go to its own stream)."""
+        if jobs == 1:
+            for _ in range(n):
+                step(0)
+            return
+        import threading
+
+        lock, left = threading.Lock(), [n]
+
+        def worker(k):
+            with torch.cuda.stream(streams[k]):
+                while True:
+                    with lock:
+                        if left[0] <= 0:
+                            break
+                        left[0] -= 1
+                    step(k)
+                streams[k].synchronize()
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(jobs)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(1, args.warmup)):
-        res, S = step()
+    S = 0
+    for k in range(NS):  # warm-up one job at a time: each model captures its frame graph here
+        with torch.cuda.stream(streams[k]):
+            for _ in range(max(1, args.warmup)):
+                res, S = step(k)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, S = step()
+    run_steps(args.steps, NS)
     barrier()
     dt = time.perf_counter() - t0
+    dt_one = None
+    if NS > 1:  # the same K steps with one job in flight, for reference
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps, 1)
+        barrier()
+        dt_one = time.perf_counter() - t1
     # the frame step on its own, HIP events on the stream the frames are launched on (torch's current stream): FRAMES single-token frames
     csm = model.model
     n = cfg["audio_num_codebooks"]
@@ -257,9 +302,10 @@ def bench_csm(args, rank, world):
         "data": "synthetic (seeded random-init CSM-1B and Mimi weights, noise reference audio, random token ids, greedy frames, EOS ignored)",
         "config": {"workload": f"CSM-1B (llama-1B backbone + llama-100M depth decoder) + Mimi codec: B={B} streams/GPU, prompt = {REF_S:.0f} s reference "
                                f"audio ({S - N_TEXT} Mimi frames incl. the EOS frame) + {N_TEXT} text ids = {S} positions, {FRAMES} frames ({FRAMES * 0.08:.0f} s) "
-                               f"generated per stream, Mimi.decode included; replicas x{world}",
+                               f"generated per stream, Mimi.decode included; replicas x{world}" + (f"; {NS} such jobs in flight per GPU (own stream, thread, model instance)" if NS > 1 else ""),
                    "global_batch": B * world, "parallelism": f"replicas x{world}"},
-        "ms_per_frame": ms_frame, "frames_per_step": FRAMES,
+        "ms_per_frame": ms_frame, "frames_per_step": FRAMES, "jobs_in_flight": NS,
+        "ms_per_step_one_job_in_flight": (dt_one / args.steps * 1e3) if dt_one is not None else None,
         "roofline": {"bound": "hbm", "kernel": "CSM frame step (five launches per Llama layer on fused_gemv_kernel; 16 + 31 x 4 layer passes)",
                      "achieved": bytes_frame / (ms_frame * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": bytes_frame / (ms_frame * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
@@ -333,7 +379,7 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         w = {k: torch.tensor(np.asarray(v, np.float32)).to(torch.bfloat16) for k, v in w.items()}  # an 8-bit checkpoint of the bf16 model
     if args.dtype == "bfloat16" and not args.quantized:
         w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
-    NS = max(1, int(args.streams))
+    NS = max(1, int(args.streams if args.streams is not None else 2))
     engs = [KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization) for _ in range(NS)]  # same weights; own workspace + graph each
     eng = engs[0]
     if args.quantized:
