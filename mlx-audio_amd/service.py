@@ -18,7 +18,7 @@ import threading
 import time
 from concurrent.futures import Future
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -79,36 +79,49 @@ def plan_pool(lengths: List[int], max_batch: int, max_pad: float = 0.25) -> List
 
 class TTSService:
     def __init__(self, model, max_batch: int = 32, max_wait_ms: float = 4.0, g2p: Optional[Callable] = None, noise_mode: Optional[int] = None,
-                 repo_id: Optional[str] = None, start: bool = True):
+                 repo_id: Optional[str] = None, start: bool = True, replicas: Sequence = ()):
         """model: a loaded kokoro.Model.  max_batch: utterances per device batch.  max_wait_ms: how long the worker waits for more
-        requests after the first one of a round (the batching window).  g2p: passed to the pipelines (tests / phoneme input)."""
+        requests after the first one of a round (the batching window).  g2p: passed to the pipelines (tests / phoneme input).
+        replicas: further loaded models of the same checkpoint (own engine, workspace, graphs).  Every model gets a worker thread with its own HIP
+        stream; rounds are dealt to whichever worker is free, so the latency-bound text / LSTM phases of one round run under the conv-bound vocoder
+        of another (bench.py's "two batches in flight": 43.8 -> 40.0 ms per B = 32 step).  A request's bits do not depend on which worker ran it."""
         from . import _lib
 
         self.model = model
+        self.models = [model, *replicas]
         self.max_batch = int(max_batch)
         self.max_wait = float(max_wait_ms) / 1e3
         self.noise_mode = _lib.NOISE_PHILOX if noise_mode is None else int(noise_mode)
         self._g2p = g2p
         self._repo_id = repo_id or getattr(model, "repo_id", None) or getattr(model, "REPO_ID", "local")
-        self._pipes: Dict[str, object] = {}
+        self._pipes: Dict[Tuple[int, str], object] = {}
         self._q: "queue.Queue[Optional[_Request]]" = queue.Queue()
         self._batch_id = 0
         self.stats = {"requests": 0, "chunks": 0, "batches": 0, "rounds": 0}
-        self._thread = None
+        self._threads: List[threading.Thread] = []
+        self._collect_lock = threading.Lock()  # one worker at a time gathers a round
+        self._state_lock = threading.Lock()    # batch ids, statistics, pipeline cache
         if start:
             self.start()
 
     # ---- life cycle
     def start(self):
-        if self._thread is None:
-            self._thread = threading.Thread(target=self._worker, name="tts-service", daemon=True)
-            self._thread.start()
+        if not self._threads:
+            self._threads = [threading.Thread(target=self._worker, args=(k,), name=f"tts-service-{k}", daemon=True) for k in range(len(self.models))]
+            for t in self._threads:
+                t.start()
 
     def close(self):
-        if self._thread is not None:
-            self._q.put(None)
-            self._thread.join()
-            self._thread = None
+        if self._threads:
+            self._q.put(None)  # every worker passes the stop marker on
+            for t in self._threads:
+                t.join()
+            self._threads = []
+            try:
+                while True:
+                    self._q.get_nowait()
+            except queue.Empty:
+                pass
 
     def __enter__(self):
         return self
@@ -132,16 +145,18 @@ class TTSService:
         return self.submit(text, **kw).result()
 
     # ---- worker
-    def _pipeline(self, lang_code: str):
+    def _pipeline(self, lang_code: str, k: int = 0):
         from .pipeline import KokoroPipeline
 
-        if lang_code not in self._pipes:
-            self._pipes[lang_code] = KokoroPipeline(lang_code=lang_code, model=self.model, repo_id=self._repo_id, g2p=self._g2p)
-        return self._pipes[lang_code]
+        with self._state_lock:
+            if (k, lang_code) not in self._pipes:
+                self._pipes[(k, lang_code)] = KokoroPipeline(lang_code=lang_code, model=self.models[k], repo_id=self._repo_id, g2p=self._g2p)
+            return self._pipes[(k, lang_code)]
 
     def _collect(self) -> Optional[List[_Request]]:
         first = self._q.get()
         if first is None:
+            self._q.put(None)  # (the next worker stops too)
             return None
         reqs, deadline = [first], time.monotonic() + self.max_wait
         while True:
@@ -155,15 +170,17 @@ class TTSService:
                 return reqs
             reqs.append(r)
 
-    def run_round(self, reqs: List[_Request]) -> None:
-        """One batching round over `reqs`: chunk, pool, batch, synthesise, hand back.  (Public for tests: a deterministic round.)"""
+    def run_round(self, reqs: List[_Request], k: int = 0) -> None:
+        """One batching round over `reqs` on model k: chunk, pool, batch, synthesise, hand back.  (Public for tests: a deterministic round.)"""
         import torch
+
+        model = self.models[k]
 
         pool = []  # (request index, position in request, phonemes, style row, speed)
         live = []
         for ri, r in enumerate(reqs):
             try:
-                pipe = self._pipeline(r.lang_code)
+                pipe = self._pipeline(r.lang_code, k)
                 if pipe.g2p is None:
                     raise TTSError(500, "no G2P available for text input (misaki is not installed); pass g2p= to TTSService")
                 pack = pipe.load_voice(r.voice)
@@ -181,34 +198,46 @@ class TTSService:
         rode: Dict[int, List[int]] = {ri: [] for ri in live}
         failed: Dict[int, Exception] = {}
         for idx in plan_pool([len(p[2]) for p in pool], self.max_batch):
-            self._batch_id += 1
+            with self._state_lock:
+                self._batch_id += 1
+                bid = self._batch_id
+                self.stats["batches"] += 1
             try:
-                res = self.model.batch_call([pool[i][2] for i in idx], np.stack([pool[i][3] for i in idx]), [pool[i][4] for i in idx],
-                                            noise_mode=self.noise_mode)
-                torch.cuda.synchronize()
+                res = model.batch_call([pool[i][2] for i in idx], np.stack([pool[i][3] for i in idx]), [pool[i][4] for i in idx],
+                                       noise_mode=self.noise_mode)
+                torch.cuda.current_stream().synchronize()  # this worker's stream only: the other workers keep running
                 for i, o in zip(idx, res):
                     outs[(pool[i][0], pool[i][1])] = o.audio[0].detach().float().cpu().numpy()
-                    if self._batch_id not in rode[pool[i][0]]:
-                        rode[pool[i][0]].append(self._batch_id)
+                    if bid not in rode[pool[i][0]]:
+                        rode[pool[i][0]].append(bid)
             except Exception as e:  # noqa: BLE001
                 for i in idx:
                     failed[pool[i][0]] = e
-            self.stats["batches"] += 1
         for ri in live:
             r = reqs[ri]
             if ri in failed:
                 r.future.set_exception(TTSError(500, f"Failed to generate: {failed[ri]}"))
                 continue
             segs = [outs[(ri, ci)] for ci in range(len(r.chunks))]
-            r.future.set_result(TTSResponse(audio=np.concatenate(segs, axis=0), sample_rate=int(self.model.sample_rate), segments=len(segs),
+            r.future.set_result(TTSResponse(audio=np.concatenate(segs, axis=0), sample_rate=int(model.sample_rate), segments=len(segs),
                                             phonemes=[ps for _, ps in r.chunks], batches=rode[ri]))
-        self.stats["requests"] += len(reqs)
-        self.stats["chunks"] += len(pool)
-        self.stats["rounds"] += 1
+        with self._state_lock:
+            self.stats["requests"] += len(reqs)
+            self.stats["chunks"] += len(pool)
+            self.stats["rounds"] += 1
 
-    def _worker(self):
+    def _worker(self, k: int = 0):
+        import torch
+
+        # worker 0 keeps the default stream (a single-model service behaves as before); the others get their own
+        stream = torch.cuda.Stream() if (k > 0 and torch.cuda.is_available()) else None
         while True:
-            reqs = self._collect()
+            with self._collect_lock:
+                reqs = self._collect()
             if reqs is None:
                 return
-            self.run_round(reqs)
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    self.run_round(reqs, k)
+            else:
+                self.run_round(reqs, k)

@@ -808,3 +808,11 @@ def test_tts_service_concurrent_requests_equal_sequential_ones(tmp_path):
         assert a.segments == b.segments == len(t.split("\n")) and a.phonemes == b.phonemes == t.split("\n")
         assert a.audio.dtype == np.float32 and a.audio.ndim == 1 and a.audio.shape[0] % 600 == 0
         np.testing.assert_array_equal(a.audio, b.audio)
+    # two models of the same checkpoint = two workers on two HIP streams: rounds overlap, every request still gets the same bits
+    model2 = Model(ModelConfig.from_dict(dict(cfg, model_type="kokoro")), weights=P.synth_checkpoint(cfg, 0))
+    with TTSService(model, max_batch=4, max_wait_ms=0.0, replicas=[model2], **kw) as svc2:
+        futs2 = [svc2.submit(texts[i % len(texts)], voice=voices[i % 2], speed=speeds[i % len(texts)], language="e") for i in range(3 * len(texts))]
+        two = [f.result(timeout=120) for f in futs2]
+    assert svc2.stats["requests"] == 3 * len(texts)
+    for i, r in enumerate(two):
+        np.testing.assert_array_equal(r.audio, seq[i % len(texts)].audio)
