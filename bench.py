@@ -382,6 +382,9 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
     NS = max(1, int(args.streams if args.streams is not None else 2))
     engs = [KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization) for _ in range(NS)]  # same weights; own workspace + graph each
     eng = engs[0]
+    if os.environ.get("KK_BENCH_FORCE"):  # A/B experiments only: kk_debug_force_generic flags (e.g. 64 = conv variant 5 where eligible)
+        for e in engs:
+            e.lib.kk_debug_force_generic(e._h, int(os.environ["KK_BENCH_FORCE"]))
     if args.quantized:
         assert eng.lib.kk_quantized_layers(eng._h) == (6 if quantization_kernel == "mxfp8" else 0)
     dev = eng.device

@@ -169,7 +169,8 @@ struct kk_model {
   bool capturing = false;
   bool no_v4 = false;
   bool no_fp8 = false;  // tests: quantised model, but the Q1 layer set runs on the bf16 kernel with the same (dequantised) weights
-  bool use_v5 = false;          // opt-in (tests / A-B): the wave-specialised persistent kernel (variant 5) where eligible; see DESIGN.md for why it is not the default
+  int v5_mode = 0;              // conv variant 5 (wave-specialised, persistent): 0 = the layers where it wins (>= 9 taps: +1.1 % on the step), 1 = wherever eligible
+                                // (tests / A-B), 2 = never
   bool no_head_fusion = false;  // tests / A-B: stand-alone conv_post + iSTFT head kernels instead of the fused head (kk_head.hip)
   bool keep_debug = false;      // tests: also materialise the tensors fused kernels skip (conv_post)
   size_t head_wf_off = 0;       // conv_post in the fused head's fragment order (bf16), 0 = not eligible
@@ -910,7 +911,14 @@ struct Ctx {
       const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4;
       g.wf = v4 ? w.wf : nullptr;
       // variant 5 (wave-specialised, persistent) takes the stride-1 convolutions; the polyphase transposed ones stay on variant 4
-      const bool v5 = v4 && m->use_v5 && B <= 256 && kk_mfma_tile_rows(Q) == 192 && kk_mfma5_eligible(g, out.dtype);
+      // measured per shape: 3-9 % faster than variant 4 on the 11-tap layers, level on 7 taps, 10-25 % slower on 3 taps
+      static int v5_min_taps = -1;
+      if (v5_min_taps < 0) {
+        const char* e = getenv("KK_V5_MIN_TAPS");  // (experiments)
+        v5_min_taps = e ? atoi(e) : 9;
+      }
+      const bool v5 = v4 && m->v5_mode != 2 && (m->v5_mode == 1 || g.Kw >= v5_min_taps) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
+                      kk_mfma5_eligible(g, out.dtype);
       prof_start();
       const int rc = v5 ? kk_launch_conv_mfma5(g, B, out.dtype, st) : v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
       prof_stop(1, flops, bytes);
@@ -1594,7 +1602,7 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
       (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4,
-      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->use_v5};
+      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->v5_mode};
   kk_model::GraphEntry* ge = nullptr;
   for (auto& g : m->graphs)
     if (g.key == key) ge = &g;
@@ -1843,7 +1851,7 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
   m->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
   m->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
-  m->use_v5 = (on & 64) != 0;          // bit 6: the wave-specialised persistent conv kernel (variant 5) where eligible, instead of variant 4
+  m->v5_mode = (on & 64) ? 1 : (on & 128) ? 2 : 0;  // bit 6: conv variant 5 (wave-specialised persistent) wherever eligible; bit 7: never (default: >= 9 taps)
 }
 
 // load_model's quantization branch (mlx_audio/tts/utils.py:241-260): the checkpoint's Linear / Embedding weights went through MLX's

@@ -672,8 +672,8 @@ def test_bf16_mode_tracks_fp32_oracle():
         _, _, it = orc.forward(utts[b], ref_s[b : b + 1], 1.0, forced_dur=durs[b], sine_noise=None, return_inter=True)
         inters.append(it)
     res = {}
-    for mode in ("mfma", "mfma_unfused", "generic", "mfma_v5"):
-        eng.lib.kk_debug_force_generic(eng._h, {"mfma": 0, "generic": 1, "mfma_unfused": 2, "mfma_v5": 64}[mode])
+    for mode in ("mfma", "mfma_unfused", "generic", "mfma_v5", "mfma_nov5"):
+        eng.lib.kk_debug_force_generic(eng._h, {"mfma": 0, "generic": 1, "mfma_unfused": 2, "mfma_v5": 64, "mfma_nov5": 128}[mode])
         eng.forward(ids, lens, torch.tensor(ref_s, device=dev), torch.ones(2, device=dev), Fmax, forced_dur=torch.tensor(durs, device=dev),
                     noise_mode=_lib.NOISE_ZERO)
         torch.cuda.synchronize()
@@ -695,8 +695,9 @@ def test_bf16_mode_tracks_fp32_oracle():
             assert res[("mfma", name, b)] < 3.0 * res[("generic", name, b)] + 5e-3, (name, b, res[("mfma", name, b)], res[("generic", name, b)])
             # fusing the statistics / AdaIN into the convs must not cost accuracy
             assert res[("mfma", name, b)] < 1.5 * res[("mfma_unfused", name, b)] + 2e-3, (name, b)
-            # the opt-in wave-specialised conv kernel (variant 5) computes the same sums in the same order as variant 4
+            # the wave-specialised conv kernel (variant 5: default on the >= 9-tap layers, everywhere eligible, nowhere) computes variant 4's sums
             assert abs(res[("mfma_v5", name, b)] - res[("mfma", name, b)]) < 2e-3, (name, b)
+            assert abs(res[("mfma_nov5", name, b)] - res[("mfma", name, b)]) < 2e-3, (name, b)
 
 
 def test_python_surface_load_model_pipeline_both_layouts(tmp_path):
