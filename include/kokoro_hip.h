@@ -195,7 +195,7 @@ void kk_debug_clear(kk_model* m);
 int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP);
 void kk_debug_set_op_wfrag(const void* w_frag);
 void kk_debug_set_op_variant(int v); /* 4 (default) or 5: which fragment-order kernel those calls use (5 = wave-specialised persistent, kk_conv_mfma5.hip) */
-void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4, bit3 quantised model without the fp8 kernel, bit4 also materialise tensors fused kernels skip, bit5 stand-alone conv_post + iSTFT kernels, bit6 variant-5 (wave-specialised persistent) conv kernel wherever eligible, bit7 never (default: the layers with >= 9 taps) */
+void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4, bit3 quantised model without the fp8 kernel, bit4 also materialise tensors fused kernels skip, bit5 stand-alone conv_post + iSTFT kernels, bit6 variant-5 (wave-specialised persistent) conv kernel wherever eligible, bit7 never (default: the layers with >= 9 taps), bit8 no side stream (the TextEncoder / harmonic-source branches of a forward on the caller's stream too) */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention

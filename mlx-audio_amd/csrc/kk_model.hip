@@ -177,6 +177,11 @@ struct kk_model {
   const bf16_t* head_wf = nullptr;
   int q_group = 0;      // kk_set_quantization: group size of the MLX affine quantisation the checkpoint went through (0 = none)
   hipStream_t cap_stream = nullptr;
+  // side stream of a forward: branches that do not depend on each other (TextEncoder beside Albert / the duration stack; the harmonic source
+  // beside the decoder) run concurrently -- the B = 1 latency is a chain of small kernels.  Fork / join through events, also inside a capture.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork[2] = {nullptr, nullptr}, side_join[2] = {nullptr, nullptr};
+  bool no_side = false;  // debug bit 8 of kk_debug_force_generic: everything on the caller's stream
   struct ProfRec { int cls; double flops; double bytes; };
   std::vector<ProfRec> prof_rec;
 };
@@ -211,6 +216,11 @@ extern "C" void kk_destroy(kk_model* m) {
   }
   if (m->seed_dev) (void)hipFree(m->seed_dev);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  for (int i = 0; i < 2; ++i) {
+    if (m->side_fork[i]) (void)hipEventDestroy(m->side_fork[i]);
+    if (m->side_join[i]) (void)hipEventDestroy(m->side_join[i]);
+  }
   delete m;
 }
 
@@ -759,6 +769,13 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   m->host.clear();
   m->pack.clear();
   m->pack.shrink_to_fit();
+  // side stream + fork / join events of a forward (Ctx::begin_side): created here, never inside a capture
+  if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess) return kk_fail("kk_finalize: hipStreamCreate failed");
+  for (int i = 0; i < 2; ++i)
+    if (hipEventCreateWithFlags(&m->side_fork[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->side_join[i], hipEventDisableTiming) != hipSuccess)
+      return kk_fail("kk_finalize: hipEventCreate failed");
+  if (getenv("KK_NO_SIDE")) m->no_side = true;  // (A/B timing / debugging: no side stream)
   m->finalized = true;
   return 0;
 }
@@ -810,7 +827,44 @@ struct ConvOpt {
 struct Ctx {
   kk_model* m;
   hipStream_t st;
+  hipStream_t main_st = nullptr;  // the caller's (or the capture) stream while a branch runs on the side stream
   bool dry;
+  // side branch k: fork_point(k) marks where its inputs are ready on the main stream; begin_side(k) ... end_side(k) brackets its launches
+  // (they go to the model's side stream); join_side(k) makes the main stream wait for it.  All no-ops in a dry run / with the debug switch.
+  // Not on the legacy NULL stream: an event recorded on / waited for by stream 0 did not order it against a non-blocking stream here (measured:
+  // the branch read its inputs early), and a blocking side stream would serialise with stream 0 anyway.  A capture runs on the model's own stream,
+  // so a replayed graph has the branches whatever stream it is launched on.
+  bool side_on() const { return !dry && !m->no_side && m->side_stream && st != nullptr; }
+  static int side_mask() {  // (debugging: KK_SIDE_MASK bit k enables branch k; default both)
+    static int v = -1;
+    if (v < 0) {
+      const char* e = getenv("KK_SIDE_MASK");
+      v = e ? atoi(e) : 3;
+    }
+    return v;
+  }
+  int fork_point(int k) {
+    if (!side_on() || !(side_mask() & (1 << k))) return 0;
+    return hipEventRecord(m->side_fork[k], st) == hipSuccess ? 0 : kk_fail("kk_forward: hipEventRecord failed");
+  }
+  int begin_side(int k) {
+    if (!side_on() || !(side_mask() & (1 << k))) return 0;
+    if (hipStreamWaitEvent(m->side_stream, m->side_fork[k], 0) != hipSuccess) return kk_fail("kk_forward: hipStreamWaitEvent failed");
+    main_st = st;
+    st = m->side_stream;
+    return 0;
+  }
+  int end_side(int k) {
+    if (!side_on() || !main_st) return 0;
+    const hipError_t e = hipEventRecord(m->side_join[k], st);
+    st = main_st;
+    main_st = nullptr;
+    return e == hipSuccess ? 0 : kk_fail("kk_forward: hipEventRecord failed");
+  }
+  int join_side(int k) {
+    if (!side_on() || !(side_mask() & (1 << k))) return 0;
+    return hipStreamWaitEvent(st, m->side_join[k], 0) == hipSuccess ? 0 : kk_fail("kk_forward: hipStreamWaitEvent failed");
+  }
   char* base;
   size_t cap, used = 0;
   int B;
@@ -1204,6 +1258,7 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
     c.q8_as = c.raw(kk_mxfp8_s_bytes((int)c.q8_rows, (int)c.q8_K));
     if (c.dry) c.q8_aq = nullptr;
   }
+  KK_TRY(c.fork_point(0));  // TextEncoder (below) needs the ids only
   // ---- Albert
   Buf e = c.act(Tmax, E), x = c.act(Tmax, hs), qkv = c.act(Tmax, 3 * hs), ctxb = c.act(Tmax, hs), att = c.act(Tmax, hs),
       ff = c.act(Tmax, cf.plbert_intermediate), tmp = c.act(Tmax, hs);
@@ -1265,8 +1320,10 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
         hipMemcpyAsync(pred_dur_out, pred_dur, (size_t)B * Tmax * 4, hipMemcpyDeviceToDevice, c.st) != hipSuccess)
       return kk_fail("kk_forward_text: copy of pred_dur failed");
   }
-  // ---- TextEncoder (modules.py:41-68)
+  // ---- TextEncoder (modules.py:41-68): independent of everything above -> the side stream (its own input-projection scratch)
   Buf te = c.act(Tmax, H), te2 = c.act(Tmax, H), t_en = c.act(Tmax, H);
+  float* xproj_te = c.f32((size_t)B * Tmax * 8 * (H / 2));
+  KK_TRY(c.begin_side(0));
   if (!c.dry) KK_TRY(kk_launch_embedding(ids, m->te_emb.p, te.p, te.bs, te.ld, H, Tmax, lT, B, te.dtype, c.st));
   for (int i = 0; i < cf.n_layer; ++i) {
     ConvOpt o;
@@ -1274,7 +1331,9 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
     KK_TRY(c.conv(m->te_cnn[i], te, lT, te2, lT, Tmax, o));
     KK_TRY(c.layernorm(te2, nullptr, te, H, Tmax, lT, m->te_ln_w[i].p, m->te_ln_b[i].p, nullptr, 0, 1e-5f, KK_ACT_LRELU, 0.2f));
   }
-  KK_TRY(c.lstm(m->text_lstm, te, 0, xproj, t_en, Tmax, lT));
+  KK_TRY(c.lstm(m->text_lstm, te, 0, xproj_te, t_en, Tmax, lT));
+  KK_TRY(c.end_side(0));
+  KK_TRY(c.join_side(0));
   KK_TRY(c.dbg("t_en", t_en, H));
   ts.d = cat;
   ts.t_en = t_en;
@@ -1363,6 +1422,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   }
   KK_TRY(c.dbg("F0_pred", f0n[0], 1));
   KK_TRY(c.dbg("N_pred", f0n[1], 1));
+  KK_TRY(c.fork_point(1));  // the harmonic source (below, after the decoder) needs the F0 curve only
   // ---- Decoder (istftnet.py:947-963)
   Buf catA = c.act(Fmax, ldcat), catB = c.act(Fmax, ldcat);
   if (!c.dry) {  // pad channels of the concat buffers feed zero weights: they must be finite
@@ -1399,6 +1459,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   // bf16: pitch 64 so the k=1 noise conv can run on the MFMA kernel; 16 spare (zero) rows so the strided noise convs can
   // read whole row groups (Packer::strided_rows)
   Buf har = c.act(c.adt == KK_BF16 ? Tf + 16 : Tf, c.adt == KK_BF16 ? 64 : 24);
+  KK_TRY(c.begin_side(1));  // source + STFT beside the decoder blocks enqueued above
   if (!c.dry && c.adt == KK_BF16 && hipMemsetAsync(har.p, 0, (size_t)B * har.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
   if (!c.dry) {
     KKSourceArgs sa;
@@ -1415,6 +1476,8 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     KK_TRY(kk_launch_stft20(har_source, Nw, lens4 + 3 * B, har.p, har.bs, har.ld, Tf, B, har.dtype, c.st));
     c.prof_stop(9, 880.0 * B * Tf, (double)B * (Nw * 4.0 + Tf * 22.0 * Ctx::esz(har.dtype)));
   }
+  KK_TRY(c.end_side(1));
+  KK_TRY(c.join_side(1));
   KK_TRY(c.dbg("har", har, 22));
   // ---- up-sampling stages (istftnet.py:776-796)
   Buf cur = gx;           // input of ups[i]
@@ -1602,7 +1665,7 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
       (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4,
-      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->v5_mode};
+      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->v5_mode, (unsigned long long)m->no_side};
   kk_model::GraphEntry* ge = nullptr;
   for (auto& g : m->graphs)
     if (g.key == key) ge = &g;
@@ -1851,6 +1914,7 @@ extern "C" void kk_debug_force_generic(kk_model* m, int on) {
   m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
   m->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
   m->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
+  m->no_side = (on & 256) != 0;        // bit 8: no side stream (every launch of a forward on the caller's stream)
   m->v5_mode = (on & 64) ? 1 : (on & 128) ? 2 : 0;  // bit 6: conv variant 5 (wave-specialised persistent) wherever eligible; bit 7: never (default: >= 9 taps)
 }
 

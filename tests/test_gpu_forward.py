@@ -333,6 +333,21 @@ def test_graph_replay_equals_eager_bitexact(dtype):
     torch.cuda.synchronize()
     assert torch.equal(wav, e6[0])
     eng.set_graph_mode(False)
+    # Side-stream branches (TextEncoder beside Albert / the duration stack, harmonic source beside the decoder): off on the legacy default
+    # stream (the eager runs above), on when the caller's stream is a real one and inside every captured graph (the replays above) -- same bits
+    s1 = torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        wav_s, pred_s, nfr_s = eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=5)
+        wav_s, pred_s, nfr_s = wav_s.clone(), pred_s.clone(), nfr_s.clone()
+    s1.synchronize()
+    assert torch.equal(wav_s, e5[0]) and torch.equal(pred_s, e5[1]) and torch.equal(nfr_s, e5[2])
+    eng.lib.kk_debug_force_generic(eng._h, 256)  # bit 8: no side stream anywhere
+    with torch.cuda.stream(s1):
+        wav_n = eng.forward(ids, lens, ref_s, sp, 110, noise_mode=_lib.NOISE_PHILOX, seed=5)[0].clone()
+    s1.synchronize()
+    eng.lib.kk_debug_force_generic(eng._h, 0)
+    assert torch.equal(wav_n, e5[0])
 
 
 @pytest.mark.parametrize("dtype,flags,size", [("float32", 0, "tiny"), ("bfloat16", 0, "tiny"), ("bfloat16", 2, "tiny"), ("bfloat16", 1, "tiny"),
