@@ -182,6 +182,48 @@ __global__ __launch_bounds__(256) void stats_partial_bf16v_kernel(KKStatsArgs a)
   }
 }
 
+
+// The same pass for ANY channel count (the decoder's 514- and 1090-channel concatenations, pitch 576 / 1152): a thread owns the 8 channels of one
+// 16-byte group of the row PITCH (pad channels are read and never reported), ldx / 8 threads cover a row, 4 rows are in flight per thread.
+// Block = ldx / 8 threads (<= 256).  Same partial layout as stats_partial_kernel; the scalar kernel took ~80 us per decoder block on these.
+__global__ __launch_bounds__(256) void stats_partial_bf16p_kernel(KKStatsArgs a) {
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int L = kk_len(a.len, b);
+  const int r0 = chunk * a.rows_per_chunk;
+  const int r1 = min(L, r0 + a.rows_per_chunk);
+  const bf16_t* xb = (const bf16_t*)a.x + (long long)b * a.xbs + tid * 8;
+  union U { uint4 u; bf16_t h[8]; };
+  float sh[8], s[8], q[8];
+  {
+    U t;
+    t.u = *(const uint4*)xb;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sh[k] = (float)t.h[k]; s[k] = 0.f; q[k] = 0.f; }
+  }
+  for (int r = r0; r < r1; r += 4) {
+    U t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i].u = *(const uint4*)(xb + (long long)(r + i < r1 ? r + i : r1 - 1) * a.ldx);  // (clamped: no load under a condition)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float live = r + i < r1 ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = ((float)t[i].h[k] - sh[k]) * live;
+        s[k] += v;
+        q[k] = __builtin_fmaf(v, v, q[k]);
+      }
+    }
+  }
+  float* pb = a.partial + ((long long)b * a.nchunk + chunk) * 2 * a.C;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = tid * 8 + k;
+    if (c < a.C) { pb[c] = s[k]; pb[a.C + c] = q[k]; }
+  }
+}
+
 // ---------------------------------------------------------------- AdaIN apply (+ act, + pool)
 __device__ __forceinline__ float act_apply(float y, int act, float slope, float alpha, bool fast) {
   if (act == KK_ACT_LRELU) return y > 0.f ? y : y * slope;
@@ -326,8 +368,11 @@ int kk_launch_instnorm_stats(KKStatsArgs a, int B, int dtype, hipStream_t st) {
     hipLaunchKernelGGL(stats_final_kernel<float>, g2, dim3(256), 0, st, a);
   } else {
     const bool vec = (a.C == 64 || a.C == 128 || a.C == 256 || a.C == 512 || a.C == 1024) && a.ldx % 8 == 0 && !((uintptr_t)a.x & 15);
+    const bool pitch = !vec && a.ldx % 8 == 0 && a.ldx / 8 <= 256 && a.C <= a.ldx && !((uintptr_t)a.x & 15) && a.C > 64;
     if (vec)
       hipLaunchKernelGGL(stats_partial_bf16v_kernel, g1, dim3(256), 0, st, a);
+    else if (pitch)
+      hipLaunchKernelGGL(stats_partial_bf16p_kernel, g1, dim3(a.ldx / 8), 0, st, a);
     else
       hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, a, cw);
     hipLaunchKernelGGL(stats_final_kernel<bf16_t>, g2, dim3(256), 0, st, a);
