@@ -350,6 +350,43 @@ def test_graph_replay_equals_eager_bitexact(dtype):
     assert torch.equal(wav_n, e5[0])
 
 
+def test_two_batches_in_flight_equal_one_at_a_time():
+    """bench.py's default (--streams 2) and TTSService(replicas=...): consecutive batches alternate over two engine instances on two HIP streams and
+    overlap on the GPU.  Every batch still gets the bits it gets alone (graph replay and eager), whichever engine / stream ran it."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.tiny_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(77)
+    utts = [rng.integers(1, 178, n).tolist() for n in (30, 11, 23, 5)]
+    engs = [_engine(cfg, w, "bfloat16") for _ in range(2)]
+    dev = engs[0].device
+    ref_s = torch.tensor(_style_rows(rng, 4), device=dev)
+    ids, lens, Tmax = engs[0].pack_ids(utts)
+    sp = torch.ones(4, device=dev)
+    want = {}
+    for seed in range(6):  # one at a time, default stream
+        want[seed] = engs[0].forward(ids, lens, ref_s, sp, 300, noise_mode=_lib.NOISE_PHILOX, seed=seed)[0].clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty_like(want[0]) for _ in range(2)]
+    for graph in (False, True):
+        for e in engs:
+            e.set_graph_mode(graph)
+        got = {}
+        for rep in range(3 if graph else 1):  # (graph mode: eager, capture, replay)
+            for seed in range(6):
+                k = seed % 2
+                with torch.cuda.stream(streams[k]):
+                    engs[k].forward(ids, lens, ref_s, sp, 300, noise_mode=_lib.NOISE_PHILOX, seed=seed, out=outs[k])
+                    got[seed] = outs[k].clone()
+        torch.cuda.synchronize()
+        for seed in range(6):
+            assert torch.equal(got[seed], want[seed]), (graph, seed)
+    for e in engs:
+        e.set_graph_mode(False)
+
+
 @pytest.mark.parametrize("dtype,flags,size", [("float32", 0, "tiny"), ("bfloat16", 0, "tiny"), ("bfloat16", 2, "tiny"), ("bfloat16", 1, "tiny"),
                                               ("bfloat16", 0, "full"), ("bfloat16", 4, "full")])
 def test_result_does_not_depend_on_workspace_contents(dtype, flags, size):
