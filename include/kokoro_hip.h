@@ -13,8 +13,10 @@
  *     beyond the call, except the weights it copied in kk_load_tensor/kk_finalize.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous; no entry
  *     point synchronises the device except kk_finalize.
- *   - a kk_model is immutable after kk_finalize and may be shared by threads that use distinct
- *     streams and workspaces (the debug hooks at the end are NOT thread safe).
+ *   - a kk_model's WEIGHTS are immutable after kk_finalize.  Its forward state is per model: the cache of captured graphs (kk_set_graph_mode)
+ *     and the side stream + fork / join events of a forward.  Concurrent batches therefore use ONE MODEL INSTANCE PER STREAM / THREAD (164 MB of
+ *     weights each; bench.py --streams, TTSService(replicas=...)).  Sharing one model between threads with distinct streams and workspaces needs
+ *     graph mode off and kk_debug_force_generic bit 8 (no side stream); the debug / profile hooks are never thread safe.
  *   - tensors are "frames-major": [B][L][C] with C contiguous.
  */
 #ifndef KOKORO_HIP_H
