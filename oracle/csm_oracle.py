@@ -87,8 +87,9 @@ class LlamaStack:
             kk = self.k[i].repeat_interleave(H // KV, dim=2)  # explicit K/V broadcast, attention.py:175-188
             vv = self.v[i].repeat_interleave(H // KV, dim=2)
             sc = torch.einsum("bshd,bthd->bhst", q, kk) * D ** -0.5
-            qpos = torch.arange(off, off + S)[:, None]
-            kpos = torch.arange(0, off + S)[None, :]
+            klen = self.k[i].shape[1]  # == off + S unless a test moved `offset` (RoPE positions) without filling the cache
+            qpos = torch.arange(klen - S, klen)[:, None]
+            kpos = torch.arange(0, klen)[None, :]
             sc = sc.masked_fill(~(kpos <= qpos)[None, None], float("-inf"))  # causal in the new block, all cached keys visible
             o = torch.einsum("bhst,bthd->bshd", torch.softmax(sc, -1), vv).reshape(B, S, H * D)
             h = h + o @ t(self.w[p + ".self_attn.o_proj.weight"]).T
