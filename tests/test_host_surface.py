@@ -217,12 +217,15 @@ def test_batch_scheduler_plans_and_keeps_text_order():
     assert [r.phonemes for r in p("\n".join(words), voice="v")] == words and all(len(c) == 1 for c in calls)  # default: chunk by chunk
 
 
-def test_chunk_planner_and_timestamps_against_golden_vectors():
-    """tests/golden/chunker_cases.json (made by tests/golden/make_golden_chunker.py): 36 random token streams -> the chunks of
-    pipeline.py:170-226, 42 (tokens, pred_dur) pairs -> the start / end times of pipeline.py:292-328, incl. too-short duration vectors."""
+def test_chunk_planner_and_timestamps_against_reference_generated_vectors():
+    """tests/golden/reference_chunker_cases.json was produced by the REFERENCE'S OWN en_tokenize / waterfall_last / tokens_to_ps /
+    tokens_to_text (pipeline.py:163-226) and join_timestamps (:292-328), compiled from the reference's source in the build container by
+    tests/golden/make_golden_reference_host.py: 36 random token streams -> chunks, 42 (tokens, pred_dur) pairs -> start / end times, incl.
+    too-short duration vectors.  (Round 2's self-generated file was byte-for-byte what the reference produces; it is gone.)"""
     from types import SimpleNamespace
 
-    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "chunker_cases.json")))
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_chunker_cases.json")))
+    assert "compiled from /root/reference" in cases["source"] and len(cases["chunk_cases"]) == 36 and len(cases["timestamp_cases"]) == 42
     p = KokoroPipeline(lang_code="a", model=False, repo_id="m")
     for c in cases["chunk_cases"]:
         objs = [SimpleNamespace(text=t, phonemes=ph, whitespace=ws) for t, ph, ws in c["tokens"]]
@@ -232,6 +235,42 @@ def test_chunk_planner_and_timestamps_against_golden_vectors():
         objs = [SimpleNamespace(text=t, phonemes=ph, whitespace=ws, start_ts=None, end_ts=None) for t, ph, ws in c["tokens"]]
         KokoroPipeline.join_timestamps(objs, np.asarray(c["pred_dur"], np.int32))
         assert [[o.start_ts, o.end_ts] for o in objs] == c["ts"]
+
+
+def test_host_functions_against_reference_generated_vectors(tmp_path):
+    """tests/golden/reference_host_cases.json (same script): the reference's check_array_shape (base.py:21-34) on every 3-D shape of the
+    Kokoro checkpoint, sanitize_lstm_weights (kokoro.py:24-44), Model.sanitize + Decoder.sanitize (kokoro.py:172-252, istftnet.py:965-979) run on
+    the PyTorch-layout checkpoints `params.to_torch_layout` makes, and load_voice_tensor (voice.py:9-81) on a torch.save'd pack."""
+    import hashlib
+
+    import torch
+
+    import mlx_audio_amd.params as P
+    from mlx_audio_amd.pipeline import load_voice_tensor
+
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_host_cases.json")))
+    for shape, want in g["check_array_shape"]:
+        assert check_array_shape(np.zeros(shape, np.int8)) is want, shape
+    # LSTM renames: params.to_torch_layout is the inverse table (the forward table lives in kk_load_tensor, exercised on the GPU by
+    # test_python_surface_load_model_pipeline_both_layouts)
+    for key, new in g["sanitize_lstm_weights"]:
+        if new != key:
+            assert list(P.to_torch_layout({new: np.zeros(1)})) == [key]
+    # reference.sanitize(to_torch_layout(w)) == w, names, shapes and values, on the tiny and the full Kokoro-82M checkpoint
+    for name, cfg in (("tiny", P.tiny_config()), ("full", P.kokoro_config(False))):
+        rec = g[f"sanitize_{name}"]
+        assert rec["equals_mlx_layout_checkpoint"] is True and rec["differing"] == []
+        inv = {n: list(s) for n, s, _ in P.param_inventory(cfg)}
+        assert rec["table"] == {k: inv[k] for k in sorted(inv)}
+    w = P.synth_checkpoint(P.tiny_config(), g["sanitize_tiny"]["seed"])  # the checkpoint the fixture was made from is today's
+    assert {k: sha(np.asarray(v, np.float32)) for k, v in sorted(w.items())} == g["sanitize_tiny"]["sha"]
+    # voice pack reader
+    vp = g["voice_pack"]
+    pack = torch.randn(510, 1, 256, generator=torch.Generator().manual_seed(vp["seed"]))
+    torch.save(pack, tmp_path / "v.pt")
+    arr = load_voice_tensor(str(tmp_path / "v.pt"))
+    assert list(arr.shape) == vp["shape"] and vp["equals_torch_tensor"] and sha(np.asarray(arr, np.float32)) == vp["sha"]
 
 
 def test_dequantize_checkpoint_honours_per_layer_group_size_and_bits():
