@@ -252,6 +252,10 @@ void kk_mimi_stream_destroy(kk_mimi_stream* s);
 int kk_mimi_stream_reset(kk_mimi_stream* s); /* MimiStreamingDecoder.reset / Mimi.reset_state (mimi.py:131-137) */
 int kk_mimi_stream_frames(const kk_mimi_stream* s);
 int kk_mimi_stream_chunk_frames(const kk_mimi_stream* s);
+/* the reference's step functions accept any number of frames per call and continue the state (mimi.py:156-168): frames per step of the
+   following calls, 1 .. the chunk_frames the stream was created with */
+int kk_mimi_stream_set_chunk(kk_mimi_stream* s, int chunk_frames);
+int kk_mimi_stream_max_chunk_frames(const kk_mimi_stream* s);
 int kk_mimi_stream_set_context(kk_mimi_stream* s, int context); /* TransformerConfig.context, default 250 (mimi.py:55-77); fresh / reset stream only */
 size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B);
 int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out);

@@ -103,6 +103,8 @@ SIGNATURES = {
     "kk_mimi_stream_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "kk_mimi_stream_create_chunked": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "kk_mimi_stream_chunk_frames": (_i, [_vp]),
+    "kk_mimi_stream_set_chunk": (_i, [_vp, _i]),
+    "kk_mimi_stream_max_chunk_frames": (_i, [_vp]),
     "kk_mimi_encode_step": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "kk_mimi_stream_destroy": (None, [_vp]),
     "kk_mimi_stream_reset": (_i, [_vp]),

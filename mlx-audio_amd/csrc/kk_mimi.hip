@@ -699,24 +699,27 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
 struct StateBuf {
   float* p = nullptr;
   int S = 0, n = 0, C = 0, maxB = 0;
-  size_t floats() const { return (size_t)maxB * (S + n) * C; }
+  int nmax = 0;  // rows of the stream's LARGEST step: the per-item pitch is (S + nmax) * C whatever this step's n is
+  size_t floats() const { return (size_t)maxB * (S + nmax) * C; }
+  long long pitch() const { return (long long)(S + nmax) * C; }
   Act all() const {
     Act t;
     t.p = p; t.rows = S + n; t.C = C; t.ld = C; t.dtype = KK_F32;
+    t.bstride = pitch();
     return t;
   }
   Act fresh() const {
     Act t;
     t.p = p + (size_t)S * C; t.rows = n; t.C = C; t.ld = C; t.dtype = KK_F32;
-    t.bstride = (long long)(S + n) * C;
+    t.bstride = pitch();
     return t;
   }
 };
 
 // rows [n, n + S) -> rows [0, S) of every item; the ranges overlap when n < S, so a block reads everything before it writes
 constexpr int SHIFT_PER_THREAD = 32;
-__global__ __launch_bounds__(256) void state_shift_kernel(float* p, int S, int n, int C) {
-  float* q = p + (long long)blockIdx.x * (S + n) * C;
+__global__ __launch_bounds__(256) void state_shift_kernel(float* p, int S, int n, int C, long long pitch) {
+  float* q = p + (long long)blockIdx.x * pitch;
   const int total = S * C;
   float v[SHIFT_PER_THREAD];
 #pragma unroll
@@ -732,15 +735,15 @@ __global__ __launch_bounds__(256) void state_shift_kernel(float* p, int S, int n
   }
 }
 // 'edge' left padding of a fresh resampler state (conv.py:265-281 with pad_mode "edge"): the carried rows repeat the first new row
-__global__ __launch_bounds__(256) void state_edge_fill_kernel(float* p, int S, int n, int C) {
-  float* q = p + (long long)blockIdx.x * (S + n) * C;
+__global__ __launch_bounds__(256) void state_edge_fill_kernel(float* p, int S, int n, int C, long long pitch) {
+  float* q = p + (long long)blockIdx.x * pitch;
   for (int e = threadIdx.x; e < S * C; e += 256) q[e] = q[(long long)S * C + e % C];
 }
 
 int state_shift(const StateBuf& b, int B, hipStream_t st) {
   if (b.S == 0) return 0;
   if (b.S * b.C > 256 * SHIFT_PER_THREAD) return kk_fail("mimi stream: carried state larger than the shift kernel takes");
-  hipLaunchKernelGGL(state_shift_kernel, dim3(B), dim3(256), 0, st, b.p, b.S, b.n, b.C);
+  hipLaunchKernelGGL(state_shift_kernel, dim3(B), dim3(256), 0, st, b.p, b.S, b.n, b.C, b.pitch());
   KK_CHECK_LAUNCH();
   return 0;
 }
@@ -751,7 +754,8 @@ struct kk_mimi_stream {
   kk_mimi* m = nullptr;
   int max_batch = 0, max_pos = 0, context = 250;
   bool encoder = false;
-  int chunk = 1;           // code frames per step
+  int chunk = 1;           // code frames of the NEXT step (kk_mimi_stream_set_chunk; the state carries over)
+  int max_chunk = 1;       // largest step the state buffers and the workspace are sized for
   float* kc = nullptr;     // [layers][maxB][max_pos][dim]
   float* vc = nullptr;
   float* rope = nullptr;   // [max_pos][hd/2][2]
@@ -795,18 +799,19 @@ int copy_rows(Run& r, const Act& src, int src_row0, const Act& dst, int rows) {
   return kk_launch_copy_slice((const float*)src.p + (size_t)src_row0 * src.ld, src.bs(), src.ld, dst.p, dst.bs(), dst.ld, 0, dst.C, rows, len, r.B, KK_F32, r.st);
 }
 
-// lays the stream's state buffers out (sizes only when pool == nullptr); returns the floats needed
+// lays the stream's state buffers out for its largest step (sizes only when pool == nullptr); returns the floats needed.  The per-item
+// pitch of every buffer is fixed by max_chunk, so the carried rows stay where they are when the step size changes (stream_set_rows)
 size_t stream_layout(kk_mimi_stream* s, float* pool) {
   const kk_mimi* m = s->m;
   const kk_mimi_config& c = m->cfg;
   const int us = c.upsample_stride, D = c.dim, mb = s->max_batch;
   size_t off = 0;
   auto place = [&](StateBuf& b, int S, int n, int C) {
-    b.S = S; b.n = n; b.C = C; b.maxB = mb;
+    b.S = S; b.n = b.nmax = n; b.C = C; b.maxB = mb;
     b.p = pool ? pool + off : nullptr;
     off += (b.floats() + 63) & ~(size_t)63;
   };
-  const int F = s->chunk;
+  const int F = s->max_chunk;
   s->up.assign(c.n_ratios, StateBuf());
   s->blk.assign(c.n_ratios, StateBuf());
   if (!s->encoder) {
@@ -833,6 +838,35 @@ size_t stream_layout(kk_mimi_stream* s, float* pool) {
     place(s->resample, us, (int)rows, D);              // conv k = 2 us, stride us: carries us rows
   }
   return off;
+}
+
+// rows every buffer takes in a step of F code frames (the same recurrences as stream_layout); pointers and pitches do not move
+void stream_set_rows(kk_mimi_stream* s, int F) {
+  const kk_mimi* m = s->m;
+  const kk_mimi_config& c = m->cfg;
+  const int us = c.upsample_stride;
+  s->chunk = F;
+  if (!s->encoder) {
+    s->resample.n = F;
+    int rows = F * us;
+    s->first.n = rows;
+    for (int l = 0; l < c.n_ratios; ++l) {
+      s->up[l].n = rows;
+      rows *= m->sea[l].ratio;
+      s->blk[l].n = rows;
+    }
+    s->last.n = rows;
+  } else {
+    long long rows = (long long)F * kk_mimi_samples_per_frame(m);
+    s->first.n = (int)rows;
+    for (int l = 0; l < c.n_ratios; ++l) {
+      s->blk[l].n = (int)rows;
+      s->up[l].n = (int)rows;
+      rows /= m->enc_sea[l].ratio;
+    }
+    s->last.n = (int)rows;
+    s->resample.n = (int)rows;
+  }
 }
 
 int stream_begin(Run& r, kk_mimi_stream* s) {  // zero state on the first step after create / reset
@@ -958,7 +992,7 @@ int run_encode_step(Run& r, kk_mimi_stream* s, const float* pcm, int* codes) {
   // downsample.step: conv k = 2 us, stride us, 'edge' left padding on the first step
   MM_TRY(copy_rows(r, x, 0, s->resample.fresh(), T));
   if (!r.dry && s->fresh) {
-    hipLaunchKernelGGL(state_edge_fill_kernel, dim3(B), dim3(256), 0, r.st, s->resample.p, s->resample.S, s->resample.n, s->resample.C);
+    hipLaunchKernelGGL(state_edge_fill_kernel, dim3(B), dim3(256), 0, r.st, s->resample.p, s->resample.S, s->resample.n, s->resample.C, s->resample.pitch());
     KK_CHECK_LAUNCH();
   }
   MM_TRY(r.conv(m->enc_down, s->resample.all(), xd, 0, 1, false, us, 0, KK_ACT_NONE, nullptr, 0));
@@ -1260,7 +1294,7 @@ static int stream_create(kk_mimi* m, bool encoder, int max_batch, int max_frames
   }
   kk_mimi_stream* s = new (std::nothrow) kk_mimi_stream();
   if (!s) return kk_fail(who, ": out of memory");
-  s->m = m; s->max_batch = max_batch; s->max_pos = max_frames * c.upsample_stride; s->encoder = encoder; s->chunk = chunk_frames;
+  s->m = m; s->max_batch = max_batch; s->max_pos = max_frames * c.upsample_stride; s->encoder = encoder; s->chunk = s->max_chunk = chunk_frames;
   const size_t D = c.dim, nl = encoder ? m->enc_layers.size() : m->layers.size(), kvn = nl * max_batch * s->max_pos * D * 4;
   std::vector<float> tab((size_t)s->max_pos * (hd / 2) * 2);
   for (int p = 0; p < s->max_pos; ++p)
@@ -1283,10 +1317,21 @@ static int stream_create(kk_mimi* m, bool encoder, int max_batch, int max_frames
 extern "C" int kk_mimi_stream_create(kk_mimi* m, int max_batch, int max_frames, kk_mimi_stream** out) {
   return stream_create(m, false, max_batch, max_frames, 1, out, "kk_mimi_stream_create");
 }
-// chunk_frames code frames per kk_mimi_decode_step / kk_mimi_encode_step call (fixed for the stream's life)
+// chunk_frames = the LARGEST number of code frames one kk_mimi_decode_step / kk_mimi_encode_step call will carry (and the size of the first
+// ones); kk_mimi_stream_set_chunk changes the size of the following steps, the state carries over
 extern "C" int kk_mimi_stream_create_chunked(kk_mimi* m, int encoder, int max_batch, int max_frames, int chunk_frames, kk_mimi_stream** out) {
   return stream_create(m, encoder != 0, max_batch, max_frames, chunk_frames, out, "kk_mimi_stream_create_chunked");
 }
+// The reference's step functions take any number of frames per call and CONTINUE the conv / KV state (mimi.py:156-168; conv.py:265-351):
+// the next steps carry `chunk_frames` code frames (1 .. the stream's largest).  The positions of one step see each other in the
+// transformer (no mask, transformer.py:79-104), so the step size is part of the result, as in the reference.
+extern "C" int kk_mimi_stream_set_chunk(kk_mimi_stream* s, int chunk_frames) {
+  if (!s || chunk_frames < 1) return kk_fail("kk_mimi_stream_set_chunk: bad argument");
+  if (chunk_frames > s->max_chunk) return kk_fail("kk_mimi_stream_set_chunk: larger than the chunk_frames the stream was created for");
+  stream_set_rows(s, chunk_frames);
+  return 0;
+}
+extern "C" int kk_mimi_stream_max_chunk_frames(const kk_mimi_stream* s) { return s ? s->max_chunk : -1; }
 extern "C" void kk_mimi_stream_destroy(kk_mimi_stream* s) {
   if (!s) return;
   for (float* p : {s->pool, s->kc, s->vc, s->rope})
@@ -1313,7 +1358,11 @@ extern "C" size_t kk_mimi_stream_workspace_bytes(kk_mimi_stream* s, int B) {
   if (!s || B < 1 || B > s->max_batch) return 0;
   Run r{s->m, nullptr, B, nullptr, 0, 0, true, false};
   r.adt = KK_F32;
-  if ((s->encoder ? run_encode_step(r, s, nullptr, nullptr) : run_decode_step(r, s, nullptr, nullptr)) != 0) return 0;
+  const int cur = s->chunk;
+  stream_set_rows(s, s->max_chunk);  // sized for the largest step: one workspace serves every step size
+  const int rc = s->encoder ? run_encode_step(r, s, nullptr, nullptr) : run_decode_step(r, s, nullptr, nullptr);
+  stream_set_rows(s, cur);
+  if (rc != 0) return 0;
   return r.used + 256;
 }
 static int step_check(kk_mimi_stream* s, bool encoder, int B, const void* in, void* workspace, size_t workspace_bytes, void* out, const char* who) {

@@ -150,15 +150,27 @@ class Mimi:
         return codes
 
     # ---- streaming (mimi.py:156-168): the state lives in library-owned stream objects, one per direction
-    def _open_stream(self, slot: str, encoder: bool, B: int, chunk: int, max_batch: int, max_frames: int):
-        """The stream of one direction; (re)created when the batch outgrows it or the chunk size changes (a fresh state either way)."""
+    def _open_stream(self, slot: str, encoder: bool, B: int, chunk: int, max_batch: int, max_frames: int, max_chunk: int = 0):
+        """The stream of one direction.  The reference's step functions take ANY number of frames per call and continue the conv / KV state
+        (mimi.py:156-168), so a call with another F continues the open stream (kk_mimi_stream_set_chunk).  The state buffers are sized for the
+        largest step, fixed when the stream is created: the first call's F, or `max_chunk`.  A fresh (or reset) stream is re-created when the
+        batch or the step outgrows it; a stream that has consumed frames cannot grow -- that is an error, never a silent restart."""
         st = self._streams.get(slot)
-        if st is None or st["maxb"] < B or st["chunk"] != chunk:
+        if st is not None and (st["maxb"] < B or st["maxchunk"] < chunk):
+            if int(self.lib.kk_mimi_stream_frames(st["h"])) > 0:
+                what = f"batch {B} > {st['maxb']}" if st["maxb"] < B else f"{chunk} frames per step > {st['maxchunk']}"
+                raise ValueError(f"Mimi stream: {what} on a stream that has already consumed frames; open it with max_batch= / max_chunk= large "
+                                 "enough for every step, or call reset_stream() first")
             self._close_slot(slot)
+            st = None
+        if st is None:
             h = C.c_void_p()
-            mb = max(B, max_batch)
-            check(self.lib.kk_mimi_stream_create_chunked(self._h, int(encoder), mb, max(max_frames, chunk), chunk, C.byref(h)), "kk_mimi_stream_create_chunked")
-            st = self._streams[slot] = {"h": h, "maxb": mb, "chunk": chunk, "ws": None}
+            mb, mc = max(B, max_batch), max(chunk, max_chunk)
+            check(self.lib.kk_mimi_stream_create_chunked(self._h, int(encoder), mb, max(max_frames, mc), mc, C.byref(h)), "kk_mimi_stream_create_chunked")
+            st = self._streams[slot] = {"h": h, "maxb": mb, "maxchunk": mc, "chunk": mc, "ws": None}
+        if st["chunk"] != chunk:
+            check(self.lib.kk_mimi_stream_set_chunk(st["h"], chunk), "kk_mimi_stream_set_chunk")
+            st["chunk"] = chunk
         need = int(self.lib.kk_mimi_stream_workspace_bytes(st["h"], B))
         if need == 0:
             raise KokoroHipError("kk_mimi_stream_workspace_bytes failed")
@@ -166,9 +178,9 @@ class Mimi:
             st["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return st
 
-    def decode_step(self, codes, max_batch: int = 0, max_frames: int = 2048) -> torch.Tensor:
-        """codes [B, nq, F] -> pcm [B, 1, 1920 * F] (the reference feeds F = 1).  The first call (or the first after reset_stream) fixes B;
-        a call with another F starts a new stream."""
+    def decode_step(self, codes, max_batch: int = 0, max_frames: int = 2048, max_chunk: int = 0) -> torch.Tensor:
+        """codes [B, nq, F] -> pcm [B, 1, 1920 * F] (the reference feeds F = 1).  The first call (or the first after reset_stream) fixes B and
+        the largest F (`max_chunk` raises it); later calls may carry fewer frames and CONTINUE the stream, as the reference's do."""
         if not self._final:
             raise KokoroHipError("Mimi.decode_step: load_weights first")
         codes = torch.as_tensor(codes).to(device=self.device, dtype=torch.int32)
@@ -177,7 +189,7 @@ class Mimi:
         B, _, F = codes.shape
         codes = codes.contiguous()
         with torch.cuda.device(self.device):
-            st = self._open_stream("dec", False, B, F, max_batch, max_frames)
+            st = self._open_stream("dec", False, B, F, max_batch, max_frames, max_chunk)
             spf = int(self.lib.kk_mimi_samples_per_frame(self._h))
             pcm = torch.empty((B, 1, spf * F), dtype=torch.float32, device=self.device)
             self._last_B = B
@@ -185,7 +197,7 @@ class Mimi:
                                                C.c_void_p(pcm.data_ptr())), "kk_mimi_decode_step")
         return pcm
 
-    def encode_step(self, xs, max_batch: int = 0, max_frames: int = 2048) -> torch.Tensor:
+    def encode_step(self, xs, max_batch: int = 0, max_frames: int = 2048, max_chunk: int = 0) -> torch.Tensor:
         """mimi.py:156-161: pcm [B, 1, 1920 * F] -> codes [B, nq, F], continuing the encoder's state.  Whole code frames only (the
         reference's modules also hold back a partial stride; a partial FRAME would return nothing until completed, so it is refused)."""
         if not self._final:
@@ -200,7 +212,7 @@ class Mimi:
         F = N // spf
         xs = xs.reshape(B, N).contiguous()
         with torch.cuda.device(self.device):
-            st = self._open_stream("enc", True, B, F, max_batch, max_frames)
+            st = self._open_stream("enc", True, B, F, max_batch, max_frames, max_chunk)
             codes = torch.empty((B, self.cfg.nq, F), dtype=torch.int32, device=self.device)
             self._last_B = B
             check(self.lib.kk_mimi_encode_step(st["h"], self._stream(), B, C.c_void_p(xs.data_ptr()), C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),

@@ -153,7 +153,7 @@ class KokoroPipeline:
         return self.voices[voice]
 
     # ---- chunk planning on duck-typed tokens (.text, .phonemes, .whitespace); behaviour of pipeline.py:163-226, pinned by
-    # tests/golden/chunker_cases.json -----------------------------------------------------------------------------------------
+    # tests/golden/reference_chunker_cases.json -----------------------------------------------------------------------------------------
     @classmethod
     def tokens_to_ps(cls, tokens) -> str:
         return _phoneme_text(tokens)
@@ -201,7 +201,7 @@ class KokoroPipeline:
     @classmethod
     def join_timestamps(cls, tokens, pred_dur) -> None:
         """Word-level start_ts / end_ts from the per-phoneme durations (behaviour of pipeline.py:292-328, pinned by
-        tests/golden/chunker_cases.json).  Time is kept in HALF frames (a frame is 1/40 s, so 80 per second) so that the pause a
+        tests/golden/reference_chunker_cases.json).  Time is kept in HALF frames (a frame is 1/40 s, so 80 per second) so that the pause a
         space character stands for can be split evenly between the word before and the word after it."""
         frames = [int(v) for v in (pred_dur.tolist() if hasattr(pred_dur, "tolist") else pred_dur)]
         if not tokens or len(frames) < 3:  # <bos>, at least one phoneme, <eos>

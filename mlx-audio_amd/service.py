@@ -106,22 +106,28 @@ class TTSService:
 
     # ---- life cycle
     def start(self):
+        self._closed = False
         if not self._threads:
             self._threads = [threading.Thread(target=self._worker, args=(k,), name=f"tts-service-{k}", daemon=True) for k in range(len(self.models))]
             for t in self._threads:
                 t.start()
 
     def close(self):
+        """Stop the workers.  Requests still queued behind the stop marker are FAILED (503), never dropped: their callers sit in
+        Future.result(); submit() after close() fails at once."""
+        self._closed = True
         if self._threads:
             self._q.put(None)  # every worker passes the stop marker on
             for t in self._threads:
                 t.join()
             self._threads = []
-            try:
-                while True:
-                    self._q.get_nowait()
-            except queue.Empty:
-                pass
+        try:
+            while True:
+                req = self._q.get_nowait()
+                if req is not None and not req.future.done():
+                    req.future.set_exception(TTSError(503, "service closed"))
+        except queue.Empty:
+            pass
 
     def __enter__(self):
         return self
@@ -132,6 +138,9 @@ class TTSService:
     # ---- the handler's entry
     def submit(self, text: str, voice: Optional[str] = None, speed: str = "1.0", language: str = "a", **_ignored) -> Future:
         fut: Future = Future()
+        if getattr(self, "_closed", False):
+            fut.set_exception(TTSError(503, "service closed"))
+            return fut
         try:
             text, voice, value, lang = parse_request(text, voice, speed, language)
         except TTSError as e:

@@ -31,6 +31,18 @@ from .mimi import Mimi, MimiStreamingDecoder
 TextLike = Union[str, Sequence[int]]
 
 
+
+@dataclass(frozen=True)
+class Sampler:
+    """What the frame loop needs of mlx_lm's `make_sampler(temp, top_k)` (sesame.py:14-17,719): the two numbers.  temp 0 = argmax."""
+    temp: float = 0.9
+    top_k: int = 50
+
+
+def make_sampler(temp: float = 0.9, top_k: int = 50, **_unused) -> Sampler:
+    return Sampler(float(temp), int(top_k))
+
+
 @dataclass
 class Segment:
     """sesame.py:418-424; `text` may be a string or the token ids of `[speaker]text` (see the module docstring)."""
@@ -336,9 +348,13 @@ class Model:
     def generate(self, text: Union[TextLike, List[TextLike]], voice: Optional[str] = None, speaker: int = 0, context: Optional[List[Segment]] = None,
                  split_pattern: Optional[str] = r"\n+", sampler: Callable = None, max_audio_length_ms: float = 90_000, ref_audio=None,
                  ref_text: Optional[TextLike] = None, stream: bool = False, streaming_interval: float = 0.5, voice_match: bool = True,
-                 temperature: float = 0.9, top_k: int = 50, seed: Optional[int] = None, stop_on_eos: bool = True, **kwargs):
-        """Yields one GenerationResult per text prompt (per `streaming_interval` seconds of frames with stream=True).  `sampler` (an MLX
-        callable in the reference) is replaced by `temperature` / `top_k` (make_sampler's arguments, sesame.py:719) + `seed`."""
+                 seed: Optional[int] = None, stop_on_eos: bool = True, **kwargs):
+        """Yields one GenerationResult per text prompt (per `streaming_interval` seconds of frames with stream=True).  `sampler` is what
+        `make_sampler(temp, top_k)` of this module returns (the reference takes mlx_lm's callable of the same name, sesame.py:719) and
+        defaults, as there, to temp 0.9 / top_k 50.  A bare `temperature=` -- generate_audio forwards its own default 0.7 to every model
+        (generate.py:288-300) -- lands in **kwargs and is IGNORED, exactly as the reference's signature ignores it."""
+        sampler = sampler or make_sampler(temp=0.9, top_k=50)
+        temperature, top_k = float(sampler.temp), int(sampler.top_k)
         context = list(context or [])
         if not context and ref_audio is not None and ref_text is not None:
             a = ref_audio.detach().cpu().numpy() if isinstance(ref_audio, torch.Tensor) else np.asarray(ref_audio, np.float32)

@@ -328,7 +328,7 @@ def test_csm_model_generate_surface_voice_match_and_stream():
     context text with the prompt and continues the context audio without an EOS frame; one GenerationResult per prompt; stream=True yields
     partial results whose concatenation has the same number of samples."""
     from mlx_audio_amd.mimi import Mimi, MimiConfig
-    from mlx_audio_amd.sesame import Model
+    from mlx_audio_amd.sesame import Model, make_sampler
 
     ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
     mcfg = P.mimi_tiny_config()
@@ -341,11 +341,11 @@ def test_csm_model_generate_surface_voice_match_and_stream():
         list(loop.generate("a string needs a tokenizer", ref_audio=ref, ref_text=ref_ids))
     with pytest.raises(FileNotFoundError):
         list(loop.generate(prompts[0]))  # no context, no ref audio: the default speaker prompt would be downloaded
-    res = list(loop.generate(prompts, ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, temperature=0.0, stop_on_eos=False))
+    res = list(loop.generate(prompts, ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, sampler=make_sampler(temp=0.0), stop_on_eos=False))
     assert len(res) == 2 and all(r.token_count == 5 and r.samples == 5 * 1920 and r.sample_rate == 24000 for r in res)
     f, m = loop.prompt_frames([type("S", (), dict(speaker=0, text=ref_ids, audio=ref))()], prompts[0], 0, voice_match=True)
     assert f.shape[0] == len(ref_ids) + len(prompts[0]) + 3 and m[-1, :4].all()  # text ids of both, then the 3 audio frames, no EOS frame
-    parts = list(loop.generate(prompts[0], ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, temperature=0.0, stop_on_eos=False,
+    parts = list(loop.generate(prompts[0], ref_audio=ref, ref_text=ref_ids, max_audio_length_ms=80 * 5, sampler=make_sampler(temp=0.0), stop_on_eos=False,
                                stream=True, streaming_interval=0.16))
     assert [p.token_count for p in parts] == [2, 2, 1] and sum(p.samples for p in parts) == res[0].samples
     # prompt_frames_batch: every stream's reference clips through as few Mimi.encode calls as their lengths allow -> the same prompts, bit for bit
@@ -372,7 +372,7 @@ def test_load_model_routes_sesame_checkpoints(tmp_path):
     from safetensors.numpy import save_file
 
     from mlx_audio_amd.mimi import Mimi, MimiConfig
-    from mlx_audio_amd.sesame import Model
+    from mlx_audio_amd.sesame import Model, make_sampler
     from mlx_audio_amd.utils import load_model
 
     ccfg = dict(P.csm_tiny_config(), audio_vocab_size=64, audio_num_codebooks=4, max_seq_len=128)
@@ -399,7 +399,7 @@ def test_load_model_routes_sesame_checkpoints(tmp_path):
     direct = Model(ccfg, mimi=Mimi(MimiConfig.from_dict(dict(mcfg)), mw), weights=cw)
     rng = np.random.default_rng(2)
     ref, ids, prompt = (0.3 * rng.standard_normal(1920 * 2)).astype(np.float32), rng.integers(0, 300, 4).tolist(), rng.integers(0, 300, 5).tolist()
-    kw = dict(ref_audio=ref, ref_text=ids, max_audio_length_ms=80 * 4, temperature=0.0, stop_on_eos=False)
+    kw = dict(ref_audio=ref, ref_text=ids, max_audio_length_ms=80 * 4, sampler=make_sampler(temp=0.0), stop_on_eos=False)
     a, b = list(model.generate(prompt, **kw)), list(direct.generate(prompt, **kw))
     assert len(a) == 1 and torch.equal(a[0].audio, b[0].audio)
 

@@ -223,7 +223,7 @@ def test_mimi_streaming_decode_matches_stream_oracle(which):
         e = err_stats(got3, ref3)
         assert got3.shape == ref3.shape and e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), (i, e)
     if which == "tiny":  # a context shorter than the history: the key range slides (transformer.py:94-98)
-        model.decode_step(torch.tensor(codes[:, :, :1]))  # back to the one-frame stream (a new chunk size opens a fresh one)
+        model.decode_step(torch.tensor(codes[:, :, :1]))  # (continues the three-frame stream with a one-frame step; reset below)
         from mlx_audio_amd import _lib
 
         dec.reset()
@@ -274,3 +274,63 @@ def test_mimi_streaming_encode_matches_stream_oracle(which):
     assert first.shape == again.shape
     with pytest.raises(ValueError):
         model.encode_step(torch.tensor(pcm[..., : spf + 5]))
+
+
+def test_mimi_stream_continues_across_step_sizes():
+    """The reference's decode_step / encode_step accept any number of frames per call and CONTINUE the conv / KV state (mimi.py:156-168,
+    conv.py:265-351): a stream fed 2, 2, 1 (then 3, 1) frames is ONE stream -- every step against MimiStreamOracle run with the same step
+    sizes, and different from a stream restarted at the size change (the final, shorter chunk used to be coded as a new
+    stream, silently).  Growing past the largest step of an open stream is an error, not a restart; max_chunk= sizes a stream up front."""
+    from mlx_audio_amd.mimi import Mimi, MimiConfig
+
+    cfg = P.mimi_tiny_config()
+    w = P.mimi_synth_checkpoint(cfg, 5, encode=True)
+    spf = int(np.prod(cfg["ratios"])) * cfg["upsample_stride"]
+    rng = np.random.default_rng(21)
+    B, steps = 2, [2, 2, 1, 2, 1]
+    Nf = sum(steps)
+    codes = rng.integers(0, cfg["bins"], (B, cfg["nq"], Nf))
+    model = Mimi(MimiConfig.from_dict(cfg), w)
+    orc = M.MimiStreamOracle(w, cfg)
+    i, outs = 0, []
+    for F in steps:
+        ref = orc.decode_step(codes[:, :, i : i + F])
+        got = model.decode_step(torch.tensor(codes[:, :, i : i + F])).cpu().numpy()
+        e = err_stats(got, ref)
+        assert got.shape == ref.shape == (B, 1, spf * F) and e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), (i, F, e)
+        outs.append(got)
+        i += F
+    assert int(model.lib.kk_mimi_stream_frames(model._streams["dec"]["h"])) == Nf
+    # restarting at the size change (what round 2 did) is a different signal: the test above is not vacuous
+    model.reset_stream()
+    model.decode_step(torch.tensor(codes[:, :, 0:2])); model.decode_step(torch.tensor(codes[:, :, 2:4]))
+    model.reset_stream()
+    restarted = model.decode_step(torch.tensor(codes[:, :, 4:5])).cpu().numpy()
+    assert np.abs(restarted - outs[2]).max() > 1e-4
+    # a step larger than the stream was opened for, mid-stream: refused loudly
+    with pytest.raises(ValueError, match="already consumed frames"):
+        model.decode_step(torch.tensor(codes[:, :, 0:3]))
+    # max_chunk= on the first call: 1, 3, 2 frames on one stream
+    model.reset_stream()
+    orc = M.MimiStreamOracle(w, cfg)
+    i = 0
+    for F in (1, 3, 2):
+        ref = orc.decode_step(codes[:, :, i : i + F])
+        got = model.decode_step(torch.tensor(codes[:, :, i : i + F]), max_chunk=3).cpu().numpy()
+        e = err_stats(got, ref)
+        assert e["max_abs"] <= 1e-3 * max(1.0, e["ref_max"]), (i, F, e)
+        i += F
+    # encode side: 2, 2, 1 frames of pcm
+    pcm = (rng.standard_normal((B, 1, 5 * spf)) * 0.3).astype(np.float32)
+    orc = M.MimiStreamOracle(w, cfg)
+    i, agree = 0, []
+    for F in (2, 2, 1):
+        ref, inter = orc.encode_step(pcm[..., i * spf : (i + F) * spf], return_inter=True)
+        got = model.encode_step(torch.tensor(pcm[..., i * spf : (i + F) * spf]))
+        torch.cuda.synchronize()
+        for name in ("seanet", "transformer", "downsampled"):
+            e = err_stats(model.debug_fetch(name).cpu().numpy(), np.transpose(inter[name], (0, 2, 1)))
+            assert e["rel_max"] < 2e-4, (F, i, name, e)
+        agree.append((got.cpu().numpy() == ref).mean())
+        i += F
+    assert min(agree) > 0.9, agree

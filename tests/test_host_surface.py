@@ -383,3 +383,26 @@ def test_csm_generate_batch_tracks_every_streams_own_eos():
     assert res.codes.shape == (3, 2, 9)
     u = [x for x in csm.uniforms if x is not None]
     assert len(u) == 12 and not torch.equal(u[0], u[1])  # seed=None still SAMPLES (fresh entropy), it does not fall back to argmax
+
+
+def test_tts_service_close_fails_queued_requests_and_later_submits():
+    """close() used to drop the requests queued behind the stop marker (their callers blocked forever in Future.result()) and
+    submit() kept enqueueing afterwards.  Both now fail with 503 at once.  No GPU: the service never starts a worker here."""
+    from mlx_audio_amd.service import TTSError, TTSService
+
+    svc = TTSService(model=object(), start=False)
+    queued = [svc.submit("hello there", "af_heart", "1.0", "a") for _ in range(3)]
+    assert not any(f.done() for f in queued)
+    svc.close()
+    for f in queued:
+        with pytest.raises(TTSError) as ei:
+            f.result(timeout=1)
+        assert ei.value.status == 503
+    late = svc.submit("too late", "af_heart", "1.0", "a")
+    with pytest.raises(TTSError) as ei:
+        late.result(timeout=1)
+    assert ei.value.status == 503 and ei.value.message == "service closed"
+    bad = TTSService(model=object(), start=False).submit("", None, "1.0", "a")  # validation errors still come first on an open service
+    with pytest.raises(TTSError) as ei:
+        bad.result(timeout=1)
+    assert ei.value.status == 400
