@@ -193,13 +193,12 @@ def bench_csm(args, rank, world):
     mcfg = P.mimi_config(32)
     mw = P.mimi_synth_checkpoint(mcfg, 0, encode=True)
     # NS jobs in flight (--streams, default 2): each job is one whole B-stream batch (prompt encode -> prompt block -> FRAMES frames -> decode) on
-    # its own HIP stream, host thread and model instance (own KV caches and graphs).  A frame is ~900 launches of a few microseconds each, so one
+    # its own HIP stream and host thread with its own KV caches and graphs on ONE shared copy of the weights.  A frame is ~900 launches of a few microseconds each, so one
     # job leaves most of the chip idle; two interleave.  The K timed steps are dealt to the jobs from one queue.
     NS = max(1, int(args.streams if args.streams is not None else 4))
-    models = []
-    for _ in range(NS):
-        mimi = Mimi(mimi_202407(32), mw, compute_dtype="bfloat16")
-        models.append(Model(cfg, mimi=mimi, weights=w, weight_dtype="bfloat16"))  # a bf16 checkpoint: matrices stored / streamed as bf16, fp32 arithmetic
+    # ONE copy of the CSM-1B and Mimi weights; every further job in flight shares them (kk_csm_share, Mimi.share: own KV caches / graphs / workspaces)
+    models = [Model(cfg, mimi=Mimi(mimi_202407(32), mw, compute_dtype="bfloat16"), weights=w, weight_dtype="bfloat16")]  # bf16 checkpoint: matrices streamed as bf16, fp32 arithmetic
+    models += [models[0].share() for _ in range(NS - 1)]
     model = models[0]
     rng = np.random.default_rng(1000 + rank)
     ctx, texts = [], []
@@ -302,7 +301,7 @@ def bench_csm(args, rank, world):
         "data": "synthetic (seeded random-init CSM-1B and Mimi weights, noise reference audio, random token ids, greedy frames, EOS ignored)",
         "config": {"workload": f"CSM-1B (llama-1B backbone + llama-100M depth decoder) + Mimi codec: B={B} streams/GPU, prompt = {REF_S:.0f} s reference "
                                f"audio ({S - N_TEXT} Mimi frames incl. the EOS frame) + {N_TEXT} text ids = {S} positions, {FRAMES} frames ({FRAMES * 0.08:.0f} s) "
-                               f"generated per stream, Mimi.decode included; replicas x{world}" + (f"; {NS} such jobs in flight per GPU (own stream, thread, model instance)" if NS > 1 else ""),
+                               f"generated per stream, Mimi.decode included; replicas x{world}" + (f"; {NS} such jobs in flight per GPU (own stream, thread, KV caches; one copy of the weights)" if NS > 1 else ""),
                    "global_batch": B * world, "parallelism": f"replicas x{world}"},
         "ms_per_frame": ms_frame, "frames_per_step": FRAMES, "jobs_in_flight": NS,
         "ms_per_step_one_job_in_flight": (dt_one / args.steps * 1e3) if dt_one is not None else None,
@@ -380,13 +379,14 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
     if args.dtype == "bfloat16" and not args.quantized:
         w = {k: torch.tensor(v).to(torch.bfloat16) for k, v in w.items()}  # the checkpoint dtype of the named config
     NS = max(1, int(args.streams if args.streams is not None else 2))
-    engs = [KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization) for _ in range(NS)]  # same weights; own workspace + graph each
+    engs = [KokoroEngine(cfg, w, compute_dtype=args.dtype, quantization=quantization)]
+    engs += [engs[0].new_context() for _ in range(NS - 1)]  # ONE kk_model (one copy of the weights); a kk_context + workspace + graph per stream
     eng = engs[0]
     if os.environ.get("KK_BENCH_FORCE"):  # A/B experiments only: kk_debug_force_generic flags (e.g. 64 = conv variant 5 where eligible)
         for e in engs:
             e.lib.kk_debug_force_generic(e._h, int(os.environ["KK_BENCH_FORCE"]))
     if args.quantized:
-        assert eng.lib.kk_quantized_layers(eng._h) == (6 if quantization_kernel == "mxfp8" else 0)
+        assert eng.quantized_layers() == (6 if quantization_kernel == "mxfp8" else 0)
     dev = eng.device
 
     # ---- synthetic workload: global batch = world * B utterances, this rank takes its contiguous shard

@@ -13,10 +13,10 @@
  *     beyond the call, except the weights it copied in kk_load_tensor/kk_finalize.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is asynchronous; no entry
  *     point synchronises the device except kk_finalize.
- *   - a kk_model's WEIGHTS are immutable after kk_finalize.  Its forward state is per model: the cache of captured graphs (kk_set_graph_mode)
- *     and the side stream + fork / join events of a forward.  Concurrent batches therefore use ONE MODEL INSTANCE PER STREAM / THREAD (164 MB of
- *     weights each; bench.py --streams, TTSService(replicas=...)).  Sharing one model between threads with distinct streams and workspaces needs
- *     graph mode off and kk_debug_force_generic bit 8 (no side stream); the debug / profile hooks are never thread safe.
+ *   - a kk_model is IMMUTABLE after kk_finalize and may be shared by any number of threads / streams (one copy of the weights).  Everything a
+ *     forward mutates -- the cache of captured graphs (kk_set_graph_mode), the side stream + fork / join events of a forward, the debug hooks
+ *     and switches, the profile brackets -- lives in a kk_context, made by kk_context_create: ONE CONTEXT PER STREAM / THREAD in flight, each with its
+ *     own caller-owned workspace (bench.py --streams, TTSService(replicas=...) share one model).  A context is not thread safe; the model is.
  *   - tensors are "frames-major": [B][L][C] with C contiguous.
  */
 #ifndef KOKORO_HIP_H
@@ -29,12 +29,13 @@
 extern "C" {
 #endif
 
-#define KK_ABI_VERSION 1
+#define KK_ABI_VERSION 2 /* 2: forward / graph / debug / profile entry points take a kk_context: round 3 */
 
 enum { KK_DTYPE_F32 = 0, KK_DTYPE_BF16 = 1, KK_DTYPE_I32 = 2, KK_DTYPE_F16 = 3 };
 enum { KK_NOISE_ZERO = 0, KK_NOISE_INJECTED = 1, KK_NOISE_PHILOX = 2 };
 
 typedef struct kk_model kk_model;
+typedef struct kk_context kk_context;
 
 /* Hyper-parameters: mlx_audio/tts/models/kokoro/kokoro.py:47-63 (ModelConfig), values pinned by
  * mlx_audio/tts/tests/test_models.py:92-122; Albert defaults mlx_audio/tts/models/kokoro/modules.py:418-435. */
@@ -73,6 +74,15 @@ int kk_finalize(kk_model* m, void* stream);
  * included) and Fmax frames (Fmax = 0: text stage only). */
 size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax);
 
+/* The per-stream run state of a finalized model (the reference's Model is one object because its forward is single threaded:
+ * kokoro.py:83-113 holds module state such as `_pipelines`, istftnet.py:526 caches the STFT).  Any number of contexts may share one model;
+ * use one per stream / thread in flight.  kk_context_workspace_bytes is kk_workspace_bytes under THIS context's debug switches (some of them
+ * materialise extra intermediates).  Destroy every context before kk_destroy(model). */
+int kk_context_create(kk_model* m, kk_context** out);
+void kk_context_destroy(kk_context* cx);
+kk_model* kk_context_model(kk_context* cx);
+size_t kk_context_workspace_bytes(const kk_context* cx, int B, int Tmax, int Fmax);
+
 /* Text stage of Model.__call__  --  kokoro.py:135-150 and :159-161:
  *   Albert -> bert_encoder -> DurationEncoder -> duration LSTM/proj -> pred_dur ; TextEncoder.
  * ids      [B][Tmax] int32, zero padded, row b = [0, ids..., 0] (kokoro.py:135)
@@ -81,7 +91,7 @@ size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax);
  * speed    [B] float32
  * pred_dur_out [B][Tmax] int32  = clip(round(sum(sigmoid(.))/speed), 1) (kokoro.py:149-150), 0 past lens[b]
  * The stage's results stay in `workspace` for kk_forward_audio. */
-int kk_forward_text(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+int kk_forward_text(kk_context* cx, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
                     const float* speed, void* workspace, size_t workspace_bytes, int32_t* pred_dur_out);
 
 /* Audio stage of Model.__call__  --  kokoro.py:151-165: alignment, F0Ntrain, Decoder, Generator, iSTFT.
@@ -91,14 +101,14 @@ int kk_forward_text(kk_model* m, void* stream, int B, int Tmax, const int32_t* i
  *           sine_noise [B][600*Fmax][9] float32, KK_NOISE_PHILOX generates it on the fly from `seed`.
  * wav_out   [B][600*Fmax] float32 (zeros past 600*nframes)   -- Output.audio, kokoro.py:165-170
  * nframes_out [B] int32 */
-int kk_forward_audio(kk_model* m, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur, int Fmax,
+int kk_forward_audio(kk_context* cx, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur, int Fmax,
                      int noise_mode, const float* sine_noise, uint64_t seed, void* workspace, size_t workspace_bytes, float* wav_out,
                      int32_t* nframes_out);
 
 /* Model.__call__ in one call (kokoro.py:120-170) without the reference's mid-forward host sync
  * (kokoro.py:151-153): durations are `forced_dur` if non-null, else the predicted ones, realised on
  * device and truncated at Fmax frames. */
-int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s, const float* speed,
+int kk_forward(kk_context* cx, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s, const float* speed,
                const int32_t* forced_dur, int Fmax, int noise_mode, const float* sine_noise, uint64_t seed, void* workspace,
                size_t workspace_bytes, float* wav_out, int32_t* pred_dur_out, int32_t* nframes_out);
 
@@ -107,7 +117,7 @@ int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, c
  * are ONE hipGraphLaunch instead of ~450 kernel launches; results are bit-identical to the eager call.  Calls with debug
  * overrides or an open profile run eagerly.  The reference has no counterpart (MLX builds its own lazy graph per call,
  * kokoro.py:120-170 is re-traced every time). */
-int kk_set_graph_mode(kk_model* m, int on);
+int kk_set_graph_mode(kk_context* cx, int on);
 
 /* load_model's quantization branch  --  mlx_audio/tts/utils.py:241-260 (nn.quantize with the class predicate of :349-369; BASELINE
  * config 5).  Call between kk_create and kk_finalize when config["quantization"] is present; the weights handed to kk_load_tensor are
@@ -187,23 +197,23 @@ int kk_op_linear_mxfp8(void* stream, const void* x_bf16, int ldx, int M, int row
  * Named intermediates of the last kk_forward*: "bert_dur" "d" "t_en" "en" "asr" "F0_pred" "N_pred" "dec_out"
  * "har_source" "har" "gen_pre_res0" "gen_stage0" "gen_pre_res1" "gen_stage1" "conv_post".
  * Data format: dense float32 [B][rows][C] on the device. */
-int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channels);
-int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst);
-int kk_debug_override(kk_model* m, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
-void kk_debug_clear(kk_model* m);
+int kk_debug_info(kk_context* cx, const char* name, int64_t* rows, int64_t* channels);
+int kk_debug_fetch(kk_context* cx, void* stream, const char* name, float* dst);
+int kk_debug_override(kk_context* cx, const char* name, const float* src); /* src must stay valid until kk_debug_clear */
+void kk_debug_clear(kk_context* cx);
 /* variant 4 of the bf16 conv kernel reads its weights in MFMA fragment order: kk_op_pack_w_frag re-lays a [Kw][CoutP][CinP] bf16
  * pack out (device to device, same size); kk_debug_set_op_wfrag(wf) makes the kk_op_conv1d_bf16* calls that follow run variant 4
  * with that pack (NULL = back to the LDS-staged kernel).  The model packs both layouts in kk_finalize. */
 int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP);
 void kk_debug_set_op_wfrag(const void* w_frag);
 void kk_debug_set_op_variant(int v); /* 4 (default) or 5: which fragment-order kernel those calls use (5 = wave-specialised persistent, kk_conv_mfma5.hip) */
-void kk_debug_force_generic(kk_model* m, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4, bit3 quantised model without the fp8 kernel, bit4 also materialise tensors fused kernels skip, bit5 stand-alone conv_post + iSTFT kernels, bit6 variant-5 (wave-specialised persistent) conv kernel wherever eligible, bit7 never (default: the layers with >= 9 taps), bit8 no side stream (the TextEncoder / harmonic-source branches of a forward on the caller's stream too) */
+void kk_debug_force_generic(kk_context* cx, int flags); /* A/B tests in bf16 mode: bit0 no MFMA kernel, bit1 MFMA without norm fusion, bit2 LDS-staged MFMA kernel instead of variant 4, bit3 quantised model without the fp8 kernel, bit4 also materialise tensors fused kernels skip, bit5 stand-alone conv_post + iSTFT kernels, bit6 variant-5 (wave-specialised persistent) conv kernel wherever eligible, bit7 never (default: the layers with >= 9 taps), bit8 no side stream (the TextEncoder / harmonic-source branches of a forward on the caller's stream too) */
 
 /* ---- per-kernel-class timing (bench.py): HIP events around every launch on the forward's stream ----
  * classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm 7 attention
  *          8 source 9 stft 10 linear_mxfp8.  kk_profile_end returns summed milliseconds, algorithmic flops / bytes and launch counts. */
-int kk_profile_begin(kk_model* m, int max_launches);
-int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count);
+int kk_profile_begin(kk_context* cx, int max_launches);
+int kk_profile_end(kk_context* cx, int ncls, double* ms, double* flops, double* bytes, int64_t* count);
 
 /* =====================================================================================================================
  * Mimi codec, decode path (CSM row C4): Mimi.decode, mlx_audio/codec/models/mimi/mimi.py:147-154.
@@ -290,6 +300,10 @@ int kk_csm_load_tensor(kk_csm* m, const char* name, const int64_t* shape, int nd
  * SwiGLU applied while the down projection stages its input; activations, accumulation, KV cache, logits stay fp32.  Before finalize. */
 int kk_csm_set_weight_dtype(kk_csm* m, int dtype);
 int kk_csm_finalize(kk_csm* m, void* stream);
+/* A second generator on the SAME device weights (immutable after kk_csm_finalize): own KV caches, positions, logits and graph cache, for another
+   stream / thread in flight; `m` must outlive it; kk_csm_setup_caches before its first frame.  (The reference's SesameModel owns its caches,
+   sesame.py:320-333, and is single threaded.) */
+int kk_csm_share(const kk_csm* m, kk_csm** out);
 int kk_csm_setup_caches(kk_csm* m, int max_batch); /* SesameModel.setup_caches (sesame.py:320-333): library-owned KV caches */
 int kk_csm_reset_caches(kk_csm* m);                /* sesame.py:338-345: positions restart at 0 */
 int kk_csm_position(const kk_csm* m);              /* tokens in the backbone cache */

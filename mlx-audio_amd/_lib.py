@@ -55,6 +55,10 @@ SIGNATURES = {
     "kk_load_tensor": (_i, [_vp, C.c_char_p, _i, C.POINTER(C.c_int64), _i, _vp]),
     "kk_finalize": (_i, [_vp, _vp]),
     "kk_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "kk_context_create": (_i, [_vp, C.POINTER(_vp)]),
+    "kk_context_destroy": (None, [_vp]),
+    "kk_context_model": (_vp, [_vp]),
+    "kk_context_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "kk_forward_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kk_forward_audio": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp, _sz, _vp, _vp]),
     "kk_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp, _sz, _vp, _vp, _vp]),
@@ -84,6 +88,7 @@ SIGNATURES = {
     "kk_csm_load_tensor": (_i, [_vp, C.c_char_p, C.POINTER(C.c_int64), _i, _vp]),
     "kk_csm_set_weight_dtype": (_i, [_vp, _i]),
     "kk_csm_finalize": (_i, [_vp, _vp]),
+    "kk_csm_share": (_i, [_vp, C.POINTER(_vp)]),
     "kk_csm_setup_caches": (_i, [_vp, _i]),
     "kk_csm_reset_caches": (_i, [_vp]),
     "kk_csm_position": (_i, [_vp]),
@@ -160,7 +165,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.kk_abi_version() != 1:
+    if lib.kk_abi_version() != 2:
         raise KokoroHipError("libkokoro_hip.so ABI version mismatch")
     _lib = lib
     return lib

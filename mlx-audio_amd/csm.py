@@ -50,6 +50,20 @@ class SesameModel:
         if weights is not None:
             self.load_weights(weights)
 
+    def share(self) -> "SesameModel":
+        """kk_csm_share: a second generator on the SAME device weights (own KV caches, positions, logits, graph cache) for another stream /
+        thread in flight.  It keeps this one alive."""
+        import copy
+
+        if not self._final:
+            raise KokoroHipError("SesameModel.share: load_weights first")
+        other = copy.copy(self)
+        h = C.c_void_p()
+        check(self.lib.kk_csm_share(self._h, C.byref(h)), "kk_csm_share")
+        other._h, other._parent = h, self
+        other._ws, other._enabled, other.max_batch, other._graph, other._gbuf = None, False, 0, False, {}
+        return other
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -306,11 +306,11 @@ int kk_launch_albert_embed(const KKEmbedArgs& a, int B, int dtype, hipStream_t s
 int kk_launch_attention(const KKAttnArgs& a, int B, int dtype, hipStream_t st) {
   if (B <= 0 || a.Tmax <= 0) return 0;
   if (a.hs != a.heads * HD) return kk_fail("attention: head size must be 64");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static KKDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attention_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-    attr_done = true;
+    attr_once.done();
   }
   dim3 grid(a.heads, B, kk_cdiv(a.Tmax, QT));
   static int no_mfma = -1;

@@ -67,3 +67,19 @@ __host__ __device__ static inline int kk_cdiv(int a, int b) { return (a + b - 1)
   } while (0)
 
 int kk_fail(const char* msg);  // records the message for kk_last_error(), returns -1
+
+// hipFuncSetAttribute state (dynamic LDS limit) is per DEVICE, not per process: one bit per device ordinal.  The call is idempotent, so two
+// threads racing through first() only repeat it.  `static KKDevOnce once; if (once.first()) { hipFuncSetAttribute(...); once.done(); }`
+#ifdef __cplusplus
+#include <atomic>
+struct KKDevOnce {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long bit() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return 1ull << (d & 63);
+  }
+  bool first() const { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
+#endif

@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
 template <typename TO, int WM, int NRM>
 int launch_one(const KKMfmaArgs& a, int B, hipStream_t st) {
   using G = Geo<2 * WM>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static KKDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)conv_mfma4_kernel<TO, WM, NRM>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_done = true;
+    attr_once.done();
   }
   const int nphase = a.mode == KK_CONVT ? a.stride : 1;
   dim3 grid(kk_cdiv(a.Q, 2 * WM), a.CoutP / BN, B * nphase);

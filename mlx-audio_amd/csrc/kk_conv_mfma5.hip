@@ -626,15 +626,18 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
 
 template <int NRM, int TPP, bool ACC>
 int launch5(const KKMfmaArgs& a, int B, hipStream_t st) {
-  static bool attr_done = false;
-  static int ncu = 0;
-  if (!attr_done) {
+  static KKDevOnce attr_once;
+  static int ncu_dev[64];  // CUs of each device this process has launched on (the persistent grid = CUs)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)conv_mfma5_kernel<NRM, TPP, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5_BYTES);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    attr_done = true;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu_dev[dev & 63] = n;
+    attr_once.done();
   }
+  const int ncu = ncu_dev[dev & 63];
   const int total = B * kk_cdiv(a.Q, BM) * (a.CoutP / BN);
   const int grid = total < ncu ? total : ncu;
   hipLaunchKernelGGL((conv_mfma5_kernel<NRM, TPP, ACC>), dim3(grid), dim3(512), LDS5_BYTES, st, a, B);

@@ -78,6 +78,7 @@ struct kk_csm {
   bool graph_mode = false;
   std::vector<GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;
+  const kk_csm* weights_of = nullptr;  // kk_csm_share: `dev` / `devb` belong to that generator (immutable after finalize), not to this one
 };
 
 namespace {
@@ -1127,12 +1128,12 @@ int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t 
     g.out = a.out + (long long)m0 * a.ors;
 #define FG_GO(MT, OCT, PRO, EPI)                                                                                                        \
   do {                                                                                                                                   \
-    static bool attr = false;                                                                                                            \
+    static KKDevOnce attr;                                                                                                               \
     const size_t lds_ = (fg_lds_bytes<MT, OCT>());                                                                                       \
-    if (!attr) {                                                                                                                         \
+    if (attr.first()) {                                                                                                                  \
       (void)hipFuncSetAttribute((const void*)fused_gemv_kernel<MT, OCT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                 (int)lds_);                                                                                              \
-      attr = true;                                                                                                                       \
+      attr.done();                                                                                                                       \
     }                                                                                                                                    \
     hipLaunchKernelGGL((fused_gemv_kernel<MT, OCT, PRO, EPI>), dim3(nblk, KS), dim3(256), lds_, st, g);                                      \
   } while (0)
@@ -1437,10 +1438,31 @@ extern "C" int kk_csm_create(const kk_csm_config* cfg, kk_csm** out) {
   return 0;
 }
 
+// A second generator on the SAME device weights: the packed matrices of a finalized generator are immutable, everything a frame mutates (KV
+// caches, positions, padding, logits, captured graphs) is per generator.  Concurrent jobs (own stream / thread each) share one copy of the
+// 1.6 B parameters this way.  `m` must outlive the generators made from it.  Call kk_csm_setup_caches on the new one.
+extern "C" int kk_csm_share(const kk_csm* m, kk_csm** out) {
+  if (!m || !out || !m->finalized) return kk_fail("kk_csm_share: needs a finalized generator");
+  kk_csm* c = new (std::nothrow) kk_csm(*m);  // descriptors + resolved device pointers of the weights
+  if (!c) return kk_fail("kk_csm_share: out of memory");
+  c->weights_of = m->weights_of ? m->weights_of : m;
+  for (Stack* s : {&c->bb, &c->dec}) {
+    s->kc = s->vc = nullptr;
+    s->offset = 0;
+    s->pos_dev = s->pad_dev = nullptr;
+  }
+  c->max_batch = 0;
+  c->dbg_logits = nullptr;
+  c->graphs.clear();
+  c->cap_stream = nullptr;
+  *out = c;
+  return 0;
+}
+
 extern "C" void kk_csm_destroy(kk_csm* m) {
   if (!m) return;
-  if (m->dev) (void)hipFree(m->dev);
-  if (m->devb) (void)hipFree(m->devb);
+  if (m->dev && !m->weights_of) (void)hipFree(m->dev);
+  if (m->devb && !m->weights_of) (void)hipFree(m->devb);
   for (Stack* s : {&m->bb, &m->dec}) {
     if (s->kc) (void)hipFree(s->kc);
     if (s->vc) (void)hipFree(s->vc);

@@ -288,11 +288,11 @@ int kk_launch_conv_post_istft(const KKHeadArgs& a, int B, hipStream_t st) {
   if (B <= 0 || a.Tfmax <= 0) return 0;
   if (a.ldx < HD_C || (a.ldx & 7) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.wf & 15)) return kk_fail("conv_post_istft: input pitch / alignment");
   if (5LL * a.Tfmax >= 0x7fffffffLL) return kk_fail("conv_post_istft: utterance too long");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static KKDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)conv_post_istft_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadGeo<256>::LDS);
     (void)hipFuncSetAttribute((const void*)conv_post_istft_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, HeadGeo<128>::LDS);
-    attr_done = true;
+    attr_once.done();
   }
   static int rows = -1;
   if (rows < 0) {

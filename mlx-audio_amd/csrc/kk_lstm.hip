@@ -164,11 +164,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int kk_launch_lstm_h256_bf16(const KKLstmArgs& a, const void* whb, int B, int dtype, hipStream_t st) {
   if (B <= 0 || a.Lmax <= 0) return 0;
   if (a.H != LH) return kk_fail("lstm_h256_bf16: H must be 256");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static KKDevOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
     (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
-    attr_done = true;
+    attr_once.done();
   }
   dim3 grid(B, 2);
   if (dtype == KK_F32)

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,7 +78,8 @@ struct kk_mimi {
   std::vector<MimiLayer> enc_layers;
   std::vector<PackedConv> cb_dot;  // per code book: E^T as a 1x1 conv qdim -> bins (the x.e term of the distance)
   PackedVec c2;                    // [nq][bins] |e|^2 / 2
-  std::map<std::string, DebugBuf> dbg;
+  std::map<std::string, DebugBuf> dbg;  // debug notes of the LAST call (any thread); dbg_mu makes concurrent callers of one codec safe
+  std::mutex dbg_mu;
 };
 
 namespace {
@@ -108,12 +110,12 @@ __global__ __launch_bounds__(256) void rvq_sum_kernel(const int* codes, const fl
 // depth-wise transposed conv, kernel 2*s, stride s, causal (last s outputs dropped): output row p = s*t + j gets
 // x[t] w[j] + x[t-1] w[j + s]
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_dw_kernel(const T* x, const float* w, int C, int ld, int Lin, int s, T* out) {
+__global__ __launch_bounds__(256) void upsample_dw_kernel(const T* x, long long xbs, const float* w, int C, int ld, int Lin, int s, T* out) {
   const int p = blockIdx.x, b = blockIdx.y;
   const int tt = p / s, j = p - tt * s;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float v = kk_ld(x + ((long long)b * Lin + tt) * ld + c) * w[(long long)j * C + c];
-    if (tt > 0) v += kk_ld(x + ((long long)b * Lin + tt - 1) * ld + c) * w[(long long)(j + s) * C + c];
+    float v = kk_ld(x + (long long)b * xbs + (long long)tt * ld + c) * w[(long long)j * C + c];
+    if (tt > 0) v += kk_ld(x + (long long)b * xbs + (long long)(tt - 1) * ld + c) * w[(long long)(j + s) * C + c];
     kk_st(out + ((long long)b * Lin * s + p) * ld + c, v);
   }
 }
@@ -562,7 +564,10 @@ struct Run {
     return kk_launch_layernorm(a, B, x.dtype, st);
   }
   void note(const char* name, const Act& t) {
-    if (!dry) m->dbg[name] = DebugBuf{t.p, t.rows, t.C, t.ld, t.bs(), B, t.dtype};
+    if (!dry) {
+      std::lock_guard<std::mutex> lk(m->dbg_mu);
+      m->dbg[name] = DebugBuf{t.p, t.rows, t.C, t.ld, t.bs(), B, t.dtype};
+    }
   }
 };
 
@@ -667,9 +672,9 @@ int run_decode(Run& r, int Nf, const int* codes, float* pcm) {
   r.note("quantized", x0);
   if (!r.dry) {
     if (bf)
-      hipLaunchKernelGGL(upsample_dw_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (const bf16_t*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (bf16_t*)xu.p);
+      hipLaunchKernelGGL(upsample_dw_kernel<bf16_t>, dim3(T, B), dim3(256), 0, r.st, (const bf16_t*)x0.p, x0.bs(), m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (bf16_t*)xu.p);
     else
-      hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (const float*)x0.p, m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (float*)xu.p);
+      hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3(T, B), dim3(256), 0, r.st, (const float*)x0.p, x0.bs(), m->up_w.p, D, x0.ld, Nf, c.upsample_stride, (float*)xu.p);
     KK_CHECK_LAUNCH();
     // xu is kept for the debug hook: the transformer updates x in place
     if (hipMemcpyAsync(x.p, xu.p, (size_t)B * T * xu.ld * (bf ? 2 : 4), hipMemcpyDeviceToDevice, r.st) != hipSuccess) return kk_fail("kk_mimi_decode: copy failed");
@@ -908,7 +913,7 @@ int run_decode_step(Run& r, kk_mimi_stream* s, const int* codes, float* pcm_out)
   // ---- upsample.step: the depthwise transposed conv over [previous | new]; its first `us` rows repeat the last step's
   if (!r.dry) {
     const Act w = s->resample.all();
-    hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3((F + 1) * us, B), dim3(256), 0, r.st, (const float*)w.p, m->up_w.p, D, w.ld, F + 1, us, (float*)xu.p);
+    hipLaunchKernelGGL(upsample_dw_kernel<float>, dim3((F + 1) * us, B), dim3(256), 0, r.st, (const float*)w.p, w.bs(), m->up_w.p, D, w.ld, F + 1, us, (float*)xu.p);
     KK_CHECK_LAUNCH();
   }
   MM_TRY(copy_rows(r, xu, us, x, F * us));
@@ -1272,7 +1277,7 @@ extern "C" int kk_mimi_decode(kk_mimi* m, void* stream, int B, int Nf, const int
   if (!m || !m->finalized) return kk_fail("kk_mimi_decode: model not finalized");
   if (B <= 0 || Nf <= 0 || !codes || !workspace || !pcm_out) return kk_fail("kk_mimi_decode: bad argument");
   if (workspace_bytes < kk_mimi_workspace_bytes(m, B, Nf)) return kk_fail("kk_mimi_decode: workspace too small");
-  m->dbg.clear();
+  { std::lock_guard<std::mutex> lk(m->dbg_mu); m->dbg.clear(); }
   Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   return run_decode(r, Nf, codes, pcm_out);
 }
@@ -1377,7 +1382,7 @@ static int step_check(kk_mimi_stream* s, bool encoder, int B, const void* in, vo
 extern "C" int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const int32_t* codes, void* workspace, size_t workspace_bytes, float* pcm_out) {
   MM_TRY(step_check(s, false, B, codes, workspace, workspace_bytes, pcm_out, "kk_mimi_decode_step"));
   s->B = B;
-  s->m->dbg.clear();
+  { std::lock_guard<std::mutex> lk(s->m->dbg_mu); s->m->dbg.clear(); }
   Run r{s->m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   r.adt = KK_F32;
   return run_decode_step(r, s, codes, pcm_out);
@@ -1386,7 +1391,7 @@ extern "C" int kk_mimi_decode_step(kk_mimi_stream* s, void* stream, int B, const
 extern "C" int kk_mimi_encode_step(kk_mimi_stream* s, void* stream, int B, const float* pcm, void* workspace, size_t workspace_bytes, int32_t* codes_out) {
   MM_TRY(step_check(s, true, B, pcm, workspace, workspace_bytes, codes_out, "kk_mimi_encode_step"));
   s->B = B;
-  s->m->dbg.clear();
+  { std::lock_guard<std::mutex> lk(s->m->dbg_mu); s->m->dbg.clear(); }
   Run r{s->m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   r.adt = KK_F32;
   return run_encode_step(r, s, pcm, codes_out);
@@ -1407,7 +1412,7 @@ extern "C" int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const floa
   if (!m->has_encoder) return kk_fail("kk_mimi_encode: the checkpoint held no encoder.* parameters");
   if (B <= 0 || N <= 0 || !pcm || !workspace || !codes_out) return kk_fail("kk_mimi_encode: bad argument");
   if (workspace_bytes < kk_mimi_encode_workspace_bytes(m, B, N)) return kk_fail("kk_mimi_encode: workspace too small");
-  m->dbg.clear();
+  { std::lock_guard<std::mutex> lk(m->dbg_mu); m->dbg.clear(); }
   Run r{m, (hipStream_t)stream, B, (char*)workspace, workspace_bytes, 0, false, false};
   return run_encode(r, N, pcm, codes_out);
 }
@@ -1415,6 +1420,7 @@ extern "C" int kk_mimi_encode(kk_mimi* m, void* stream, int B, int N, const floa
 // named intermediates of the LAST decode call (tests): "quantized", "upsampled", "transformer", "layer0".."layer3"
 extern "C" int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, int64_t* channels) {
   if (!m || !name) return kk_fail("kk_mimi_debug_info: bad argument");
+  std::lock_guard<std::mutex> lk(m->dbg_mu);
   auto it = m->dbg.find(name);
   if (it == m->dbg.end()) return kk_fail("kk_mimi_debug_info: unknown stage");
   if (rows) *rows = it->second.rows;
@@ -1423,6 +1429,7 @@ extern "C" int kk_mimi_debug_info(kk_mimi* m, const char* name, int64_t* rows, i
 }
 extern "C" int kk_mimi_debug_fetch(kk_mimi* m, void* stream, const char* name, float* dst) {
   if (!m || !name || !dst) return kk_fail("kk_mimi_debug_fetch: bad argument");
+  std::lock_guard<std::mutex> lk(m->dbg_mu);
   auto it = m->dbg.find(name);
   if (it == m->dbg.end()) return kk_fail("kk_mimi_debug_fetch: unknown stage");
   const DebugBuf& d = it->second;

@@ -148,6 +148,16 @@ struct kk_model {
   VecW sp_wT, sp_b, sd_wT, sd_b;  // prosody half (ref_s[128:]) / decoder half (ref_s[:128])
   int Np = 0, Nd = 0;
 
+  size_t head_wf_off = 0;       // conv_post in the fused head's fragment order (bf16), 0 = not eligible
+  const bf16_t* head_wf = nullptr;
+  int q_group = 0;      // kk_set_quantization: group size of the MLX affine quantisation the checkpoint went through (0 = none)
+};
+
+// Everything a forward MUTATES lives here, not in the model: the cache of captured graphs, the side stream and its fork / join events, the debug
+// hooks and switches, the profile brackets.  A kk_model is immutable after kk_finalize and is shared by any number of contexts; one context serves
+// one stream / thread at a time ("a kk_model is immutable after finalize and may be shared by threads using distinct streams + workspaces").
+struct kk_context {
+  kk_model* m = nullptr;
   std::map<std::string, DebugEntry> dbg;
   std::map<std::string, const float*> dbg_over;
 
@@ -173,9 +183,6 @@ struct kk_model {
                                 // (tests / A-B), 2 = never
   bool no_head_fusion = false;  // tests / A-B: stand-alone conv_post + iSTFT head kernels instead of the fused head (kk_head.hip)
   bool keep_debug = false;      // tests: also materialise the tensors fused kernels skip (conv_post)
-  size_t head_wf_off = 0;       // conv_post in the fused head's fragment order (bf16), 0 = not eligible
-  const bf16_t* head_wf = nullptr;
-  int q_group = 0;      // kk_set_quantization: group size of the MLX affine quantisation the checkpoint went through (0 = none)
   hipStream_t cap_stream = nullptr;
   // side stream of a forward: branches that do not depend on each other (TextEncoder beside Albert / the duration stack; the harmonic source
   // beside the decoder) run concurrently -- the B = 1 latency is a chain of small kernels.  Fork / join through events, also inside a capture.
@@ -209,20 +216,47 @@ extern "C" int kk_create(const kk_config* cfg, kk_model** out) {
 extern "C" void kk_destroy(kk_model* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
-  for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
-  for (auto& g : m->graphs) {
+  delete m;
+}
+
+// A context on a finalized model: the side stream + fork / join events of a forward (Ctx::begin_side) are created here, never inside a capture.
+extern "C" int kk_context_create(kk_model* m, kk_context** out) {
+  if (!m || !out) return kk_fail("kk_context_create: null argument");
+  if (!m->finalized) return kk_fail("kk_context_create: kk_finalize has not been called");
+  kk_context* cx = new (std::nothrow) kk_context();
+  if (!cx) return kk_fail("kk_context_create: out of memory");
+  cx->m = m;
+  bool ok = hipStreamCreateWithFlags(&cx->side_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipEventCreateWithFlags(&cx->side_fork[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&cx->side_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    kk_context_destroy(cx);
+    return kk_fail("kk_context_create: hipStreamCreate / hipEventCreate failed");
+  }
+  if (getenv("KK_NO_SIDE")) cx->no_side = true;  // (A/B timing / debugging: no side stream)
+  *out = cx;
+  return 0;
+}
+
+extern "C" void kk_context_destroy(kk_context* cx) {
+  if (!cx) return;
+  for (hipEvent_t e : cx->prof_ev) (void)hipEventDestroy(e);
+  for (auto& g : cx->graphs) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (g.graph) (void)hipGraphDestroy(g.graph);
   }
-  if (m->seed_dev) (void)hipFree(m->seed_dev);
-  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  if (cx->seed_dev) (void)hipFree(cx->seed_dev);
+  if (cx->cap_stream) (void)hipStreamDestroy(cx->cap_stream);
+  if (cx->side_stream) (void)hipStreamDestroy(cx->side_stream);
   for (int i = 0; i < 2; ++i) {
-    if (m->side_fork[i]) (void)hipEventDestroy(m->side_fork[i]);
-    if (m->side_join[i]) (void)hipEventDestroy(m->side_join[i]);
+    if (cx->side_fork[i]) (void)hipEventDestroy(cx->side_fork[i]);
+    if (cx->side_join[i]) (void)hipEventDestroy(cx->side_join[i]);
   }
-  delete m;
+  delete cx;
 }
+
+extern "C" kk_model* kk_context_model(kk_context* cx) { return cx ? cx->m : nullptr; }
 
 static float bf16_to_f32(uint16_t v) {
   uint32_t u = (uint32_t)v << 16;
@@ -769,13 +803,6 @@ extern "C" int kk_finalize(kk_model* m, void* stream) {
   m->host.clear();
   m->pack.clear();
   m->pack.shrink_to_fit();
-  // side stream + fork / join events of a forward (Ctx::begin_side): created here, never inside a capture
-  if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess) return kk_fail("kk_finalize: hipStreamCreate failed");
-  for (int i = 0; i < 2; ++i)
-    if (hipEventCreateWithFlags(&m->side_fork[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->side_join[i], hipEventDisableTiming) != hipSuccess)
-      return kk_fail("kk_finalize: hipEventCreate failed");
-  if (getenv("KK_NO_SIDE")) m->no_side = true;  // (A/B timing / debugging: no side stream)
   m->finalized = true;
   return 0;
 }
@@ -826,6 +853,7 @@ struct ConvOpt {
 
 struct Ctx {
   kk_model* m;
+  kk_context* cx = nullptr;  // the switches it carries shape the allocation plan too, so even a dry run has one
   hipStream_t st;
   hipStream_t main_st = nullptr;  // the caller's (or the capture) stream while a branch runs on the side stream
   bool dry;
@@ -834,7 +862,7 @@ struct Ctx {
   // Not on the legacy NULL stream: an event recorded on / waited for by stream 0 did not order it against a non-blocking stream here (measured:
   // the branch read its inputs early), and a blocking side stream would serialise with stream 0 anyway.  A capture runs on the model's own stream,
   // so a replayed graph has the branches whatever stream it is launched on.
-  bool side_on() const { return !dry && !m->no_side && m->side_stream && st != nullptr; }
+  bool side_on() const { return !dry && !cx->no_side && cx->side_stream && st != nullptr; }
   static int side_mask() {  // (debugging: KK_SIDE_MASK bit k enables branch k; default both)
     static int v = -1;
     if (v < 0) {
@@ -845,25 +873,25 @@ struct Ctx {
   }
   int fork_point(int k) {
     if (!side_on() || !(side_mask() & (1 << k))) return 0;
-    return hipEventRecord(m->side_fork[k], st) == hipSuccess ? 0 : kk_fail("kk_forward: hipEventRecord failed");
+    return hipEventRecord(cx->side_fork[k], st) == hipSuccess ? 0 : kk_fail("kk_forward: hipEventRecord failed");
   }
   int begin_side(int k) {
     if (!side_on() || !(side_mask() & (1 << k))) return 0;
-    if (hipStreamWaitEvent(m->side_stream, m->side_fork[k], 0) != hipSuccess) return kk_fail("kk_forward: hipStreamWaitEvent failed");
+    if (hipStreamWaitEvent(cx->side_stream, cx->side_fork[k], 0) != hipSuccess) return kk_fail("kk_forward: hipStreamWaitEvent failed");
     main_st = st;
-    st = m->side_stream;
+    st = cx->side_stream;
     return 0;
   }
   int end_side(int k) {
     if (!side_on() || !main_st) return 0;
-    const hipError_t e = hipEventRecord(m->side_join[k], st);
+    const hipError_t e = hipEventRecord(cx->side_join[k], st);
     st = main_st;
     main_st = nullptr;
     return e == hipSuccess ? 0 : kk_fail("kk_forward: hipEventRecord failed");
   }
   int join_side(int k) {
     if (!side_on() || !(side_mask() & (1 << k))) return 0;
-    return hipStreamWaitEvent(st, m->side_join[k], 0) == hipSuccess ? 0 : kk_fail("kk_forward: hipStreamWaitEvent failed");
+    return hipStreamWaitEvent(st, cx->side_join[k], 0) == hipSuccess ? 0 : kk_fail("kk_forward: hipStreamWaitEvent failed");
   }
   char* base;
   size_t cap, used = 0;
@@ -889,26 +917,26 @@ struct Ctx {
 
   // ---- profiling: bracket a launch with events (only when kk_profile_begin was called)
   void prof_start() {
-    if (dry || !m->prof_on) return;
-    const size_t i = m->prof_rec.size();
-    if (2 * i + 1 >= m->prof_ev.size()) return;
-    (void)hipEventRecord(m->prof_ev[2 * i], st);
+    if (dry || !cx->prof_on) return;
+    const size_t i = cx->prof_rec.size();
+    if (2 * i + 1 >= cx->prof_ev.size()) return;
+    (void)hipEventRecord(cx->prof_ev[2 * i], st);
   }
   void prof_stop(int cls, double flops, double bytes) {
-    if (dry || !m->prof_on) return;
-    const size_t i = m->prof_rec.size();
-    if (2 * i + 1 >= m->prof_ev.size()) return;
-    (void)hipEventRecord(m->prof_ev[2 * i + 1], st);
-    m->prof_rec.push_back({cls, flops, bytes});
+    if (dry || !cx->prof_on) return;
+    const size_t i = cx->prof_rec.size();
+    if (2 * i + 1 >= cx->prof_ev.size()) return;
+    (void)hipEventRecord(cx->prof_ev[2 * i + 1], st);
+    cx->prof_rec.push_back({cls, flops, bytes});
   }
   static double esz(int dt) { return dt == KK_F32 ? 4.0 : 2.0; }
 
   int dbg(const char* name, const Buf& b, int C) {
     if (dry) return 0;
-    auto it = m->dbg_over.find(name);
-    if (it != m->dbg_over.end())
+    auto it = cx->dbg_over.find(name);
+    if (it != cx->dbg_over.end())
       KK_TRY(kk_launch_convert(it->second, KK_F32, (long long)b.rows * C, C, b.p, b.dtype, b.bs, b.ld, C, b.rows, B, st));
-    m->dbg[name] = DebugEntry{b.p, b.ld, b.bs, b.rows, C, b.dtype, B};
+    cx->dbg[name] = DebugEntry{b.p, b.ld, b.bs, b.rows, C, b.dtype, B};
     return 0;
   }
 
@@ -962,7 +990,7 @@ struct Ctx {
         g.stat_ntiles = last_ntiles;
       }
       // variant 4 (W fragments straight into registers): bf16 outputs at the default 192-row tile
-      const bool v4 = w.wf && out.dtype == KK_BF16 && !m->no_v4;
+      const bool v4 = w.wf && out.dtype == KK_BF16 && !cx->no_v4;
       g.wf = v4 ? w.wf : nullptr;
       // variant 5 (wave-specialised, persistent) takes the stride-1 convolutions; the polyphase transposed ones stay on variant 4
       // measured per shape: 3-9 % faster than variant 4 on the 11-tap layers, level on 7 taps, 10-25 % slower on 3 taps
@@ -971,7 +999,7 @@ struct Ctx {
         const char* e = getenv("KK_V5_MIN_TAPS");  // (experiments)
         v5_min_taps = e ? atoi(e) : 9;
       }
-      const bool v5 = v4 && m->v5_mode != 2 && (m->v5_mode == 1 || g.Kw >= v5_min_taps) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
+      const bool v5 = v4 && cx->v5_mode != 2 && (cx->v5_mode == 1 || g.Kw >= v5_min_taps) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
                       kk_mfma5_eligible(g, out.dtype);
       prof_start();
       const int rc = v5 ? kk_launch_conv_mfma5(g, B, out.dtype, st) : v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
@@ -990,7 +1018,7 @@ struct Ctx {
   void* q8_as = nullptr;
   size_t q8_rows = 0, q8_K = 0;
   bool can_fp8(const ConvW& w, const Buf& x, KKLen lin, const Buf& out, KKLen lout, int Q, const ConvOpt& o) const {
-    return w.fp8 && !m->no_fp8 && !m->force_generic && q8_aq && x.dtype == KK_BF16 && out.dtype == KK_BF16 && w.Kw == 1 && o.mode == KK_CONV &&
+    return w.fp8 && !cx->no_fp8 && !cx->force_generic && q8_aq && x.dtype == KK_BF16 && out.dtype == KK_BF16 && w.Kw == 1 && o.mode == KK_CONV &&
            o.stride == 1 && o.pad == 0 && o.dil == 1 && o.in_shift == 0 && o.in_slope == 1.f && !o.res && o.scale == 1.f && !o.accumulate &&
            (o.act == KK_ACT_NONE || o.act == KK_ACT_GELU) && !o.nrm_a && !o.want_stats && x.rows == out.rows && Q == x.rows &&
            x.bs == (long long)x.rows * x.ld && out.bs == (long long)out.rows * out.ld && x.ld % 8 == 0 && !((uintptr_t)x.p & 15) &&
@@ -1003,7 +1031,7 @@ struct Ctx {
     const bool cout_ok = w.Cout == w.Cout8 || (out.ld >= w.Cout8 && !o.res && !o.accumulate && o.pad_out_ok);
     return w.mfma && cout_ok && x.dtype == KK_BF16 && (out.dtype == KK_BF16 || out.dtype == KK_F32) && (!o.res || o.res->dtype == out.dtype) &&
            kk_mfma_eligible(w.Cin, w.Cout8, w.Kw, o.mode, o.stride, o.dil) && x.ld >= w.CinP && x.ld % 8 == 0 && out.ld % 8 == 0 &&
-           (!o.res || o.res->ld % 8 == 0) && al16 && !m->force_generic;
+           (!o.res || o.res->ld % 8 == 0) && al16 && !cx->force_generic;
   }
 
   // ---- fused-norm plumbing (bf16 MFMA path) ------------------------------------------------------------------
@@ -1102,7 +1130,7 @@ struct Ctx {
     memset(&a, 0, sizeof a);
     a.xproj = xproj; a.whT = l.whT.p; a.out = out.p; a.obs = out.bs; a.ldo = out.ld; a.H = l.H; a.Lmax = Lmax; a.len = len;
     prof_start();
-    const int rc = (l.whb && adt == KK_BF16 && !m->force_generic) ? kk_launch_lstm_h256_bf16(a, l.whb, B, out.dtype, st)
+    const int rc = (l.whb && adt == KK_BF16 && !cx->force_generic) ? kk_launch_lstm_h256_bf16(a, l.whb, B, out.dtype, st)
                                                                     : kk_launch_lstm(a, B, out.dtype, st);
     prof_stop(4, 2.0 * B * Lmax * 2 * 4 * l.H * l.H, 2.0 * Lmax * 4 * l.H * l.H * 4.0 * B);
     return rc;
@@ -1123,7 +1151,7 @@ int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in
     p1.pad = p2.pad = 1;
     p2.res = r.learned ? &out : &x;
     const Buf& c1in = r.up ? bufA : x;
-    if (c.adt == KK_BF16 && c.fz_part && !c.m->no_fusion && c.can_mfma(r.conv1, c1in, bufB, p1) && c.can_mfma(r.conv2, bufB, out, p2) &&
+    if (c.adt == KK_BF16 && c.fz_part && !c.cx->no_fusion && c.can_mfma(r.conv1, c1in, bufB, p1) && c.can_mfma(r.conv2, bufB, out, p2) &&
         (!r.learned || c.can_mfma(r.sc, x, out, ConvOpt()))) {
       float *pa = nullptr, *pb = nullptr;
       KK_TRY(c.stats(x, r.Cin, Lmax_in, lin));
@@ -1185,7 +1213,7 @@ int run_resblock1(Ctx& c, const ResBlock1& r, const Buf& x_in, const Buf& y, Buf
     ConvOpt p1, p2;
     p1.dil = r.dil[2]; p1.pad = (r.k * r.dil[2] - r.dil[2]) / 2;
     p2.pad = (r.k - 1) / 2; p2.res = &x_in;
-    if (c.adt == KK_BF16 && c.fz_part && !c.m->no_fusion && c.can_mfma(r.c1[0], x_in, t2, p1) && c.can_mfma(r.c2[0], t2, y, p2) &&
+    if (c.adt == KK_BF16 && c.fz_part && !c.cx->no_fusion && c.can_mfma(r.c1[0], x_in, t2, p1) && c.can_mfma(r.c2[0], t2, y, p2) &&
         (!acc || c.can_mfma(r.c2[2], t2, *acc, p2))) {
       // bf16 MFMA path: 2 convs + 2 tiny parameter folds per iteration, 5 tensor passes instead of 12
       float *pa = nullptr, *pb = nullptr;
@@ -1248,6 +1276,8 @@ struct TextState {  // results of the text stage that the audio stage consumes
 
 int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref_s, const float* speed, TextState& ts, int* pred_dur_out) {
   kk_model* m = c.m;
+  kk_context* cx = c.cx;
+  (void)cx;
   const kk_config& cf = m->cfg;
   const int H = cf.hidden_dim, hs = cf.plbert_hidden, E = cf.plbert_embedding, B = c.B;
   const KKLen lT{lens, 1, 0};
@@ -1344,6 +1374,8 @@ int run_text(Ctx& c, int Tmax, const int* ids, const int* lens, const float* ref
 int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* dur, int Fmax, int noise_mode, const float* noise,
               uint64_t seed, const TextState& ts, float* wav_out, int* nframes_out) {
   kk_model* m = c.m;
+  kk_context* cx = c.cx;
+  (void)cx;
   const kk_config& cf = m->cfg;
   const int H = cf.hidden_dim, S = cf.style_dim, DH = cf.decoder_hidden, B = c.B;
   const int u0 = cf.upsample_rates[0], u1 = cf.upsample_rates[1], hop = cf.gen_istft_hop_size;
@@ -1465,7 +1497,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     KKSourceArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.f0 = (const float*)f0n[0].p; sa.L2max = L2; sa.len2 = lens4; sa.phase = phase; sa.lin_w = m->lin_w.p; sa.lin_b = m->lin_b;
-    sa.noise = noise; sa.seed = seed; sa.seed_dev = m->capturing ? m->seed_dev : nullptr; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
+    sa.noise = noise; sa.seed = seed; sa.seed_dev = cx->capturing ? cx->seed_dev : nullptr; sa.noise_mode = noise_mode; sa.har_source = har_source; sa.Nmax = Nw; sa.upsample = u0 * u1 * hop;
     c.prof_start();
     KK_TRY(kk_launch_source(sa, B, c.st));
     c.prof_stop(8, 0.0, (double)B * Nw * 4.0);
@@ -1496,10 +1528,10 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
       on.stride = sf0;
       on.pad = (sf0 + 1) / 2;
     }
-    const bool fuse_ok = c.adt == KK_BF16 && c.fz_part && !m->no_fusion && !m->force_generic;
+    const bool fuse_ok = c.adt == KK_BF16 && c.fz_part && !cx->no_fusion && !cx->force_generic;
     bool xsrc_stats = false, xi_stats = false;
     const ConvW& nrows = m->noise_conv_rows[i];
-    if (!last && nrows.mfma && c.adt == KK_BF16 && !m->force_generic && har.ld == 64 && on.stride <= 16 && nrows.Cin == on.stride * har.ld) {
+    if (!last && nrows.mfma && c.adt == KK_BF16 && !cx->force_generic && har.ld == 64 && on.stride <= 16 && nrows.Cin == on.stride * har.ld) {
       // stride-1 form over groups of `stride` rows (see Packer::strided_rows): valid groups = ceil(len / stride) = lst + 1
       Buf hg = har;
       hg.ld = on.stride * har.ld;
@@ -1552,17 +1584,17 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   }
   // ---- conv_post + iSTFT head (istftnet.py:798-806)
   Buf cp = c.act(Tf, 24);
-  if (m->head_wf && !m->no_head_fusion && !m->force_generic && cur.dtype == KK_BF16 && cur.ld % 8 == 0 && cur.ld >= m->conv_post.Cin &&
-      !((uintptr_t)cur.p & 15) && m->dbg_over.find("conv_post") == m->dbg_over.end()) {
+  if (m->head_wf && !cx->no_head_fusion && !cx->force_generic && cur.dtype == KK_BF16 && cur.ld % 8 == 0 && cur.ld >= m->conv_post.Cin &&
+      !((uintptr_t)cur.p & 15) && cx->dbg_over.find("conv_post") == cx->dbg_over.end()) {
     // one kernel: the 22-channel tensor never exists in HBM (kk_head.hip); `keep_debug` also writes it for kk_debug_fetch
     if (!c.dry) {
       KKHeadArgs h;
       memset(&h, 0, sizeof h);
       h.x = (const bf16_t*)cur.p; h.xbs = cur.bs; h.ldx = cur.ld; h.wf = m->head_wf; h.bias = m->conv_post.b; h.in_slope = 0.01f;
       h.len_frames = lens4 + 2 * B; h.Tfmax = Tf; h.wav = wav_out; h.wbs = (long long)Nw;
-      if (m->keep_debug) { h.cp_out = (bf16_t*)cp.p; h.cp_bs = cp.bs; h.cp_ld = cp.ld; }
+      if (cx->keep_debug) { h.cp_out = (bf16_t*)cp.p; h.cp_bs = cp.bs; h.cp_ld = cp.ld; }
       for (int n = 0; n < 20; ++n) h.hann_per[n] = (float)(0.5 * (1.0 - cos(2.0 * 3.14159265358979323846 * n / 20.0)));
-      if (m->keep_debug && hipMemsetAsync(cp.p, 0, (size_t)B * cp.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
+      if (cx->keep_debug && hipMemsetAsync(cp.p, 0, (size_t)B * cp.bs * 2, c.st) != hipSuccess) return kk_fail("kk_forward_audio: memset failed");
       c.prof_start();
       KK_TRY(kk_launch_conv_post_istft(h, B, c.st));
       // algorithmic bytes of the fused head: 128 bf16 channels in + 5 fp32 samples out per frame column
@@ -1595,10 +1627,10 @@ int check_common(kk_model* m, int B, int Tmax, const char* who) {
 
 }  // namespace
 
-extern "C" size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax) {
+static size_t plan_bytes(const kk_model* m, kk_context* cx, int B, int Tmax, int Fmax) {
   if (!m || !m->finalized || B <= 0 || Tmax <= 0) return 0;
   Ctx c;
-  c.m = const_cast<kk_model*>(m); c.st = nullptr; c.dry = true; c.base = nullptr; c.cap = 0; c.used = 0;
+  c.m = const_cast<kk_model*>(m); c.cx = cx; c.st = nullptr; c.dry = true; c.base = nullptr; c.cap = 0; c.used = 0;
   c.B = B;
   c.adt = m->adt;
   TextState ts;
@@ -1606,35 +1638,49 @@ extern "C" size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fma
   if (Fmax > 0 && run_audio(c, Tmax, nullptr, nullptr, nullptr, Fmax, 0, nullptr, 0, ts, nullptr, nullptr) != 0) return 0;
   return c.used + 256;
 }
+// (a context with default switches; the debug switches of a real context can change which intermediates exist: kk_context_workspace_bytes)
+extern "C" size_t kk_workspace_bytes(const kk_model* m, int B, int Tmax, int Fmax) {
+  kk_context def;
+  def.m = const_cast<kk_model*>(m);
+  return plan_bytes(m, &def, B, Tmax, Fmax);
+}
+extern "C" size_t kk_context_workspace_bytes(const kk_context* cx, int B, int Tmax, int Fmax) {
+  return cx ? plan_bytes(cx->m, const_cast<kk_context*>(cx), B, Tmax, Fmax) : 0;
+}
 
-static int make_ctx(kk_model* m, void* stream, int B, void* ws, size_t ws_bytes, Ctx& c) {
-  c.m = m; c.st = (hipStream_t)stream; c.dry = false; c.base = (char*)ws; c.cap = ws_bytes; c.used = 0; c.B = B; c.adt = m->adt;
+static int make_ctx(kk_context* cx, void* stream, int B, void* ws, size_t ws_bytes, Ctx& c) {
+  kk_model* m = cx->m;
+  c.m = m; c.cx = cx; c.st = (hipStream_t)stream; c.dry = false; c.base = (char*)ws; c.cap = ws_bytes; c.used = 0; c.B = B; c.adt = m->adt;
   if (!ws) return kk_fail("workspace is null");
   if (((uintptr_t)ws & 255) != 0) return kk_fail("workspace must be 256-byte aligned");
   return 0;
 }
 
-extern "C" int kk_forward_text(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+extern "C" int kk_forward_text(kk_context* cx, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
                                const float* speed, void* workspace, size_t workspace_bytes, int32_t* pred_dur_out) {
+  if (!cx) return kk_fail("kk_forward_text: null context");
+  kk_model* m = cx->m;
   KK_TRY(check_common(m, B, Tmax, "kk_forward_text"));
   if (!ids || !lens || !ref_s || !speed) return kk_fail("kk_forward_text: null input");
-  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, 0)) return kk_fail("kk_forward_text: workspace too small");
+  if (workspace_bytes < kk_context_workspace_bytes(cx, B, Tmax, 0)) return kk_fail("kk_forward_text: workspace too small");
   Ctx c;
-  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
+  KK_TRY(make_ctx(cx, stream, B, workspace, workspace_bytes, c));
   TextState ts;
   return run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out);
 }
 
-extern "C" int kk_forward_audio(kk_model* m, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur,
+extern "C" int kk_forward_audio(kk_context* cx, void* stream, int B, int Tmax, const int32_t* lens, const float* ref_s, const int32_t* dur,
                                 int Fmax, int noise_mode, const float* sine_noise, uint64_t seed, void* workspace, size_t workspace_bytes,
                                 float* wav_out, int32_t* nframes_out) {
+  if (!cx) return kk_fail("kk_forward_audio: null context");
+  kk_model* m = cx->m;
   KK_TRY(check_common(m, B, Tmax, "kk_forward_audio"));
   if (!lens || !ref_s || !dur || !wav_out || Fmax <= 0) return kk_fail("kk_forward_audio: bad argument");
   if (noise_mode == KK_NOISE_INJECTED && !sine_noise) return kk_fail("kk_forward_audio: KK_NOISE_INJECTED needs sine_noise");
-  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, Fmax)) return kk_fail("kk_forward_audio: workspace too small");
+  if (workspace_bytes < kk_context_workspace_bytes(cx, B, Tmax, Fmax)) return kk_fail("kk_forward_audio: workspace too small");
   // replay the text stage's allocation plan (no launches) to find where its results live in the workspace
   Ctx c;
-  KK_TRY(make_ctx(m, stream, B, workspace, workspace_bytes, c));
+  KK_TRY(make_ctx(cx, stream, B, workspace, workspace_bytes, c));
   TextState ts;
   c.dry = true;
   KK_TRY(run_text(c, Tmax, nullptr, nullptr, nullptr, nullptr, ts, nullptr));
@@ -1642,60 +1688,62 @@ extern "C" int kk_forward_audio(kk_model* m, void* stream, int B, int Tmax, cons
   return run_audio(c, Tmax, lens, ref_s, dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
 }
 
-extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
+extern "C" int kk_forward(kk_context* cx, void* stream, int B, int Tmax, const int32_t* ids, const int32_t* lens, const float* ref_s,
                           const float* speed, const int32_t* forced_dur, int Fmax, int noise_mode, const float* sine_noise, uint64_t seed,
                           void* workspace, size_t workspace_bytes, float* wav_out, int32_t* pred_dur_out, int32_t* nframes_out) {
+  if (!cx) return kk_fail("kk_forward: null context");
+  kk_model* m = cx->m;
   KK_TRY(check_common(m, B, Tmax, "kk_forward"));
   if (!ids || !lens || !ref_s || !speed || !wav_out || Fmax <= 0) return kk_fail("kk_forward: bad argument");
   if (noise_mode == KK_NOISE_INJECTED && !sine_noise) return kk_fail("kk_forward: KK_NOISE_INJECTED needs sine_noise");
-  if (workspace_bytes < kk_workspace_bytes(m, B, Tmax, Fmax)) return kk_fail("kk_forward: workspace too small");
+  if (workspace_bytes < kk_context_workspace_bytes(cx, B, Tmax, Fmax)) return kk_fail("kk_forward: workspace too small");
   auto eager = [&](void* on_stream) -> int {
     Ctx c;
-    KK_TRY(make_ctx(m, on_stream, B, workspace, workspace_bytes, c));
+    KK_TRY(make_ctx(cx, on_stream, B, workspace, workspace_bytes, c));
     TextState ts;
     KK_TRY(run_text(c, Tmax, ids, lens, ref_s, speed, ts, pred_dur_out));
     return run_audio(c, Tmax, lens, ref_s, forced_dur ? forced_dur : ts.pred_dur, Fmax, noise_mode, sine_noise, seed, ts, wav_out, nframes_out);
   };
   // ---- graph replay: ~450 launches become one hipGraphLaunch.  Only for the plain forward: no debug overrides, no profiling.
-  if (!m->graph_mode || m->prof_on || !m->dbg_over.empty()) return eager(stream);
+  if (!cx->graph_mode || cx->prof_on || !cx->dbg_over.empty()) return eager(stream);
   hipStream_t st = (hipStream_t)stream;
   const std::vector<unsigned long long> key = {(unsigned long long)B, (unsigned long long)Tmax, (unsigned long long)Fmax,
       (unsigned long long)noise_mode, (unsigned long long)(uintptr_t)ids, (unsigned long long)(uintptr_t)lens,
       (unsigned long long)(uintptr_t)ref_s, (unsigned long long)(uintptr_t)speed, (unsigned long long)(uintptr_t)forced_dur,
       (unsigned long long)(uintptr_t)sine_noise, (unsigned long long)(uintptr_t)workspace, (unsigned long long)workspace_bytes,
       (unsigned long long)(uintptr_t)wav_out, (unsigned long long)(uintptr_t)pred_dur_out, (unsigned long long)(uintptr_t)nframes_out,
-      (unsigned long long)m->force_generic, (unsigned long long)m->no_fusion, (unsigned long long)m->no_v4,
-      (unsigned long long)m->no_head_fusion, (unsigned long long)m->keep_debug, (unsigned long long)m->v5_mode, (unsigned long long)m->no_side};
-  kk_model::GraphEntry* ge = nullptr;
-  for (auto& g : m->graphs)
+      (unsigned long long)cx->force_generic, (unsigned long long)cx->no_fusion, (unsigned long long)cx->no_v4,
+      (unsigned long long)cx->no_head_fusion, (unsigned long long)cx->keep_debug, (unsigned long long)cx->v5_mode, (unsigned long long)cx->no_side};
+  kk_context::GraphEntry* ge = nullptr;
+  for (auto& g : cx->graphs)
     if (g.key == key) ge = &g;
   if (!ge) {
-    if (m->graphs.size() >= 16) {  // drop the oldest entry
-      if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
-      if (m->graphs.front().graph) (void)hipGraphDestroy(m->graphs.front().graph);
-      m->graphs.erase(m->graphs.begin());
+    if (cx->graphs.size() >= 16) {  // drop the oldest entry
+      if (cx->graphs.front().exec) (void)hipGraphExecDestroy(cx->graphs.front().exec);
+      if (cx->graphs.front().graph) (void)hipGraphDestroy(cx->graphs.front().graph);
+      cx->graphs.erase(cx->graphs.begin());
     }
-    m->graphs.emplace_back();
-    ge = &m->graphs.back();
+    cx->graphs.emplace_back();
+    ge = &cx->graphs.back();
     ge->key = key;
   }
   if (ge->seen == 0) {  // first sight of this argument tuple: run eagerly (one-time attribute calls must not land in a capture)
     ge->seen = 1;
     return eager(stream);
   }
-  if (!m->seed_dev && hipMalloc((void**)&m->seed_dev, 8) != hipSuccess) return kk_fail("kk_forward: hipMalloc(seed) failed");
+  if (!cx->seed_dev && hipMalloc((void**)&cx->seed_dev, 8) != hipSuccess) return kk_fail("kk_forward: hipMalloc(seed) failed");
   if (ge->seen == 1) {
     // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured); nothing runs
     // during capture, and the instantiated graph is launched on the caller's stream
-    if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
+    if (!cx->cap_stream && hipStreamCreateWithFlags(&cx->cap_stream, hipStreamNonBlocking) != hipSuccess)
       return kk_fail("kk_forward: hipStreamCreate failed");
-    if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    if (hipStreamBeginCapture(cx->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
       return kk_fail("kk_forward: hipStreamBeginCapture failed");
-    m->capturing = true;
-    const int rc = eager((void*)m->cap_stream);
-    m->capturing = false;
+    cx->capturing = true;
+    const int rc = eager((void*)cx->cap_stream);
+    cx->capturing = false;
     hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+    const hipError_t e = hipStreamEndCapture(cx->cap_stream, &g);
     if (rc != 0) {
       if (g) (void)hipGraphDestroy(g);
       return rc;
@@ -1711,14 +1759,14 @@ extern "C" int kk_forward(kk_model* m, void* stream, int B, int Tmax, const int3
     ge->seen = 2;
   }
   // the seed is the one by-value argument that changes between replays: it travels through device memory
-  KK_TRY(kk_launch_set_u64(m->seed_dev, seed, st));
+  KK_TRY(kk_launch_set_u64(cx->seed_dev, seed, st));
   if (hipGraphLaunch(ge->exec, st) != hipSuccess) return kk_fail("kk_forward: hipGraphLaunch failed");
   return 0;
 }
 
-extern "C" int kk_set_graph_mode(kk_model* m, int on) {
-  if (!m) return kk_fail("kk_set_graph_mode: null model");
-  m->graph_mode = on != 0;
+extern "C" int kk_set_graph_mode(kk_context* cx, int on) {
+  if (!cx) return kk_fail("kk_set_graph_mode: null context");
+  cx->graph_mode = on != 0;
   return 0;
 }
 
@@ -1886,36 +1934,36 @@ extern "C" int kk_op_conv_post_istft(void* stream, int B, const void* x, int ldx
 // ------------------------------------------------------------------------------------------------
 // debug hooks
 // ------------------------------------------------------------------------------------------------
-extern "C" int kk_debug_info(kk_model* m, const char* name, int64_t* rows, int64_t* channels) {
-  if (!m || !name) return kk_fail("kk_debug_info: null argument");
-  auto it = m->dbg.find(name);
-  if (it == m->dbg.end()) return failf("kk_debug_info: no intermediate named %s in the last forward", name);
+extern "C" int kk_debug_info(kk_context* cx, const char* name, int64_t* rows, int64_t* channels) {
+  if (!cx || !name) return kk_fail("kk_debug_info: null argument");
+  auto it = cx->dbg.find(name);
+  if (it == cx->dbg.end()) return failf("kk_debug_info: no intermediate named %s in the last forward", name);
   if (rows) *rows = it->second.rows;
   if (channels) *channels = it->second.C;
   return 0;
 }
-extern "C" int kk_debug_fetch(kk_model* m, void* stream, const char* name, float* dst) {
-  if (!m || !name || !dst) return kk_fail("kk_debug_fetch: null argument");
-  auto it = m->dbg.find(name);
-  if (it == m->dbg.end()) return failf("kk_debug_fetch: no intermediate named %s in the last forward", name);
+extern "C" int kk_debug_fetch(kk_context* cx, void* stream, const char* name, float* dst) {
+  if (!cx || !name || !dst) return kk_fail("kk_debug_fetch: null argument");
+  auto it = cx->dbg.find(name);
+  if (it == cx->dbg.end()) return failf("kk_debug_fetch: no intermediate named %s in the last forward", name);
   const DebugEntry& e = it->second;
   return kk_launch_convert(e.p, e.dtype, e.bs, e.ld, dst, KK_F32, (long long)e.rows * e.C, e.C, e.C, e.rows, e.B, (hipStream_t)stream);
 }
-extern "C" int kk_debug_override(kk_model* m, const char* name, const float* src) {
-  if (!m || !name || !src) return kk_fail("kk_debug_override: null argument");
-  m->dbg_over[name] = src;
+extern "C" int kk_debug_override(kk_context* cx, const char* name, const float* src) {
+  if (!cx || !name || !src) return kk_fail("kk_debug_override: null argument");
+  cx->dbg_over[name] = src;
   return 0;
 }
-extern "C" void kk_debug_force_generic(kk_model* m, int on) {
-  if (!m) return;
-  m->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
-  m->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
-  m->no_v4 = (on & 4) != 0;          // bit 2: the LDS-staged MFMA kernel (variant 2) instead of variant 4
-  m->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
-  m->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
-  m->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
-  m->no_side = (on & 256) != 0;        // bit 8: no side stream (every launch of a forward on the caller's stream)
-  m->v5_mode = (on & 64) ? 1 : (on & 128) ? 2 : 0;  // bit 6: conv variant 5 (wave-specialised persistent) wherever eligible; bit 7: never (default: >= 9 taps)
+extern "C" void kk_debug_force_generic(kk_context* cx, int on) {
+  if (!cx) return;
+  cx->force_generic = (on & 1) != 0;  // bit 0: no MFMA kernel at all
+  cx->no_fusion = (on & 2) != 0;      // bit 1: MFMA convs, but stand-alone statistics / AdaIN kernels
+  cx->no_v4 = (on & 4) != 0;          // bit 2: the LDS-staged MFMA kernel (variant 2) instead of variant 4
+  cx->no_fp8 = (on & 8) != 0;         // bit 3: quantised model, Q1 layer set on the bf16 kernel (same dequantised weights)
+  cx->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
+  cx->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
+  cx->no_side = (on & 256) != 0;        // bit 8: no side stream (every launch of a forward on the caller's stream)
+  cx->v5_mode = (on & 64) ? 1 : (on & 128) ? 2 : 0;  // bit 6: conv variant 5 (wave-specialised persistent) wherever eligible; bit 7: never (default: >= 9 taps)
 }
 
 // load_model's quantization branch (mlx_audio/tts/utils.py:241-260): the checkpoint's Linear / Embedding weights went through MLX's
@@ -1968,40 +2016,40 @@ extern "C" void kk_debug_set_op_variant(int v) { g_op_variant = v == 5 ? 5 : 4; 
 extern "C" int kk_op_pack_w_frag(void* stream, const void* w_bf16, void* w_frag, int Kw, int CoutP, int CinP) {
   return kk_launch_pack_w_frag(w_bf16, w_frag, Kw, CoutP, CinP, (hipStream_t)stream);
 }
-extern "C" void kk_debug_clear(kk_model* m) {
-  if (!m) return;
-  m->dbg_over.clear();
-  m->dbg.clear();
+extern "C" void kk_debug_clear(kk_context* cx) {
+  if (!cx) return;
+  cx->dbg_over.clear();
+  cx->dbg.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
 // per-kernel-class timing (bench.py / profiling only)
 // ------------------------------------------------------------------------------------------------
-extern "C" int kk_profile_begin(kk_model* m, int max_launches) {
-  if (!m || max_launches <= 0) return kk_fail("kk_profile_begin: bad argument");
-  while ((int)m->prof_ev.size() < 2 * max_launches) {
+extern "C" int kk_profile_begin(kk_context* cx, int max_launches) {
+  if (!cx || max_launches <= 0) return kk_fail("kk_profile_begin: bad argument");
+  while ((int)cx->prof_ev.size() < 2 * max_launches) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return kk_fail("kk_profile_begin: hipEventCreate failed");
-    m->prof_ev.push_back(e);
+    cx->prof_ev.push_back(e);
   }
-  m->prof_rec.clear();
-  m->prof_on = true;
+  cx->prof_rec.clear();
+  cx->prof_on = true;
   return 0;
 }
 // Sums the recorded launches per class: ms[cls], flops[cls], bytes[cls], count[cls] for cls < ncls.  Synchronises the
 // events it reads.  Classes: 0 conv_generic 1 conv_mfma 2 instnorm_stats 3 adain_act 4 lstm 5 istft_head 6 layernorm
 // 7 attention 8 source 9 stft
-extern "C" int kk_profile_end(kk_model* m, int ncls, double* ms, double* flops, double* bytes, int64_t* count) {
-  if (!m || !ms || !flops || !bytes || !count) return kk_fail("kk_profile_end: null argument");
+extern "C" int kk_profile_end(kk_context* cx, int ncls, double* ms, double* flops, double* bytes, int64_t* count) {
+  if (!cx || !ms || !flops || !bytes || !count) return kk_fail("kk_profile_end: null argument");
   for (int i = 0; i < ncls; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; count[i] = 0; }
-  m->prof_on = false;
-  for (size_t i = 0; i < m->prof_rec.size(); ++i) {
-    if (hipEventSynchronize(m->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: event sync failed");
+  cx->prof_on = false;
+  for (size_t i = 0; i < cx->prof_rec.size(); ++i) {
+    if (hipEventSynchronize(cx->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: event sync failed");
     float t = 0.f;
-    if (hipEventElapsedTime(&t, m->prof_ev[2 * i], m->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: elapsed failed");
-    const auto& r = m->prof_rec[i];
+    if (hipEventElapsedTime(&t, cx->prof_ev[2 * i], cx->prof_ev[2 * i + 1]) != hipSuccess) return kk_fail("kk_profile_end: elapsed failed");
+    const auto& r = cx->prof_rec[i];
     if (r.cls >= 0 && r.cls < ncls) { ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; count[r.cls] += 1; }
   }
-  m->prof_rec.clear();
+  cx->prof_rec.clear();
   return 0;
 }

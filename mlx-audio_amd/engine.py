@@ -38,31 +38,21 @@ def make_kk_config(cfg: dict, compute_dtype: str = "float32") -> KKConfig:
 _NP2KK = {np.dtype(np.float32): _lib.KK_F32, np.dtype(np.float16): _lib.KK_F16}
 
 
-class KokoroEngine:
-    """Owns a finalized kk_model on one GPU and runs batches of utterances through it."""
+class _SharedModel:
+    """One finalized, IMMUTABLE kk_model (the weights on the device), shared by every engine / context made from it; destroyed when the last
+    of them is gone."""
 
-    def __init__(self, cfg: dict, weights: Dict[str, np.ndarray], compute_dtype: str = "float32", device: Optional[torch.device] = None,
-                 quantization: Optional[dict] = None):
-        if not torch.cuda.is_available():
-            raise _lib.KokoroHipError("KokoroEngine needs a GPU (torch.cuda.is_available() is False)")
-        self.lib = _lib.load()
-        self.cfg = cfg
-        self.compute_dtype = compute_dtype
-        self.device = device or torch.device("cuda", torch.cuda.current_device())
-        self._h = C.c_void_p()
+    def __init__(self, lib, cfg: dict, weights, compute_dtype: str, device, quantization: Optional[dict]):
+        self.lib = lib
+        self.h = C.c_void_p()
         kc = make_kk_config(cfg, compute_dtype)
-        check(self.lib.kk_create(C.byref(kc), C.byref(self._h)), "kk_create")
-        self.quantization = quantization
+        check(lib.kk_create(C.byref(kc), C.byref(self.h)), "kk_create")
         if quantization is not None:  # load_model's quantization branch (tts/utils.py:241-260): `weights` are the dequantised ones
-            check(self.lib.kk_set_quantization(self._h, int(quantization["group_size"]), int(quantization["bits"])), "kk_set_quantization")
+            check(lib.kk_set_quantization(self.h, int(quantization["group_size"]), int(quantization["bits"])), "kk_set_quantization")
         for name, arr in weights.items():
             self._load(name, arr)
-        with torch.cuda.device(self.device):
-            check(self.lib.kk_finalize(self._h, self._stream()), "kk_finalize")
-        self._ws = None
-        self._graph = False
-        self._graph_bufs = {}
-        self.upsample = int(np.prod(cfg["istftnet"]["upsample_rates"])) * cfg["istftnet"]["gen_istft_hop_size"] * 2  # samples / frame
+        with torch.cuda.device(device):
+            check(lib.kk_finalize(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "kk_finalize")
 
     def _load(self, name: str, arr) -> None:
         if isinstance(arr, torch.Tensor):
@@ -79,12 +69,57 @@ class KokoroEngine:
                 raw = raw.astype(np.float32)
                 dt = _lib.KK_F32
         shape = (C.c_int64 * raw.ndim)(*raw.shape)
-        check(self.lib.kk_load_tensor(self._h, name.encode(), dt, shape, raw.ndim, raw.ctypes.data_as(C.c_void_p)), f"kk_load_tensor({name})")
+        check(self.lib.kk_load_tensor(self.h, name.encode(), dt, shape, raw.ndim, raw.ctypes.data_as(C.c_void_p)), f"kk_load_tensor({name})")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.h.value:
+                self.lib.kk_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class KokoroEngine:
+    """One kk_context (graph cache, side stream, debug / profile state) + its workspace on a finalized kk_model, and the batch helpers.
+    `new_context()` gives a sibling engine on the SAME model (one copy of the weights): one engine per stream / thread in flight."""
+
+    def __init__(self, cfg: dict, weights: Optional[Dict[str, np.ndarray]] = None, compute_dtype: str = "float32", device: Optional[torch.device] = None,
+                 quantization: Optional[dict] = None, share: Optional["KokoroEngine"] = None):
+        if not torch.cuda.is_available():
+            raise _lib.KokoroHipError("KokoroEngine needs a GPU (torch.cuda.is_available() is False)")
+        self.lib = _lib.load()
+        if share is not None:
+            cfg, compute_dtype, device, quantization = share.cfg, share.compute_dtype, share.device, share.quantization
+        self.cfg = cfg
+        self.compute_dtype = compute_dtype
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.quantization = quantization
+        self._model = share._model if share is not None else _SharedModel(self.lib, cfg, weights, compute_dtype, self.device, quantization)
+        self._m = self._model.h  # kk_model*: immutable, shared
+        self._h = C.c_void_p()   # kk_context*: this engine's own
+        with torch.cuda.device(self.device):
+            check(self.lib.kk_context_create(self._m, C.byref(self._h)), "kk_context_create")
+        self._ws = None
+        self._graph = False
+        self._graph_bufs = {}
+        self.upsample = int(np.prod(cfg["istftnet"]["upsample_rates"])) * cfg["istftnet"]["gen_istft_hop_size"] * 2  # samples / frame
+
+    def new_context(self) -> "KokoroEngine":
+        """A second context on the same weights (own graph cache, side stream, workspace): for another stream / thread in flight."""
+        return KokoroEngine(self.cfg, share=self)
+
+    def quantized_layers(self) -> int:
+        return int(self.lib.kk_quantized_layers(self._m))
+
+    def force(self, flags: int) -> None:
+        """kk_debug_force_generic on this context (A/B tests)."""
+        self.lib.kk_debug_force_generic(self._h, int(flags))
 
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:
-                self.lib.kk_destroy(self._h)
+                self.lib.kk_context_destroy(self._h)  # before the model: _model is released after this
                 self._h = C.c_void_p()
         except Exception:
             pass
@@ -93,7 +128,7 @@ class KokoroEngine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def workspace(self, B: int, Tmax: int, Fmax: int) -> torch.Tensor:
-        n = int(self.lib.kk_workspace_bytes(self._h, B, Tmax, Fmax))
+        n = int(self.lib.kk_context_workspace_bytes(self._h, B, Tmax, Fmax))
         if n == 0:
             raise _lib.KokoroHipError("kk_workspace_bytes returned 0")
         if self._ws is None or self._ws.numel() < n:
@@ -176,11 +211,11 @@ class KokoroEngine:
         # the workspace must be the one kk_forward_text just used (same B, Tmax).  The text stage's results live in its first
         # kk_workspace_bytes(B, Tmax, 0) bytes at offsets that do not depend on Fmax (bump allocation in a fixed order), so a workspace that
         # is too small for this Fmax -- the caller only learns Fmax from the predicted durations -- is re-allocated and that prefix copied
-        need = int(self.lib.kk_workspace_bytes(self._h, B, Tmax, Fmax))
+        need = int(self.lib.kk_context_workspace_bytes(self._h, B, Tmax, Fmax))
         if self._ws is None:
             raise _lib.KokoroHipError("forward_audio: run forward_text first (its results live in the workspace)")
         if self._ws.numel() < need:
-            keep = min(int(self.lib.kk_workspace_bytes(self._h, B, Tmax, 0)), self._ws.numel())
+            keep = min(int(self.lib.kk_context_workspace_bytes(self._h, B, Tmax, 0)), self._ws.numel())
             grown = torch.empty(need, dtype=torch.uint8, device=self.device)
             grown[:keep].copy_(self._ws[:keep])
             self._ws = grown

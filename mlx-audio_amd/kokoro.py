@@ -86,6 +86,16 @@ class Model:
         """Layout normalisation happens inside kk_load_tensor (by expected shape); nothing to do on the host."""
         return weights
 
+    def new_context(self) -> "Model":
+        """A second Model on the SAME device weights (one kk_model, a new kk_context: own graph cache, side stream, workspace) for another
+        stream / thread in flight (TTSService(contexts=N), bench.py --streams).  The reference's Model is single threaded (kokoro.py:83-113)."""
+        import copy
+
+        other = copy.copy(self)
+        other._pipelines = {}
+        other._engine = self.engine.new_context()
+        return other
+
     @property
     def engine(self) -> KokoroEngine:
         if self._engine is None:

@@ -73,14 +73,24 @@ class Mimi:
         if weights is not None:
             self.load_weights(weights)
 
+    def share(self) -> "Mimi":
+        """A second Mimi on the SAME kk_mimi (its weights are immutable after finalize; decode / encode take a caller-owned workspace and the
+        streaming state lives in stream objects): own workspace and streams, for another HIP stream / host thread in flight.  Keeps this one
+        alive; only the original destroys the codec."""
+        import copy
+
+        other = copy.copy(self)
+        other._parent, other._ws, other._streams = self, None, {}
+        return other
+
     def __del__(self):
         try:
             for st in getattr(self, "_streams", {}).values():
                 self.lib.kk_mimi_stream_destroy(st["h"])
             self._streams = {}
-            if getattr(self, "_h", None):
+            if getattr(self, "_h", None) and getattr(self, "_parent", None) is None:
                 self.lib.kk_mimi_destroy(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 

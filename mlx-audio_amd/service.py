@@ -79,16 +79,18 @@ def plan_pool(lengths: List[int], max_batch: int, max_pad: float = 0.25) -> List
 
 class TTSService:
     def __init__(self, model, max_batch: int = 32, max_wait_ms: float = 4.0, g2p: Optional[Callable] = None, noise_mode: Optional[int] = None,
-                 repo_id: Optional[str] = None, start: bool = True, replicas: Sequence = ()):
+                 repo_id: Optional[str] = None, start: bool = True, replicas: Sequence = (), contexts: int = 1):
         """model: a loaded kokoro.Model.  max_batch: utterances per device batch.  max_wait_ms: how long the worker waits for more
         requests after the first one of a round (the batching window).  g2p: passed to the pipelines (tests / phoneme input).
-        replicas: further loaded models of the same checkpoint (own engine, workspace, graphs).  Every model gets a worker thread with its own HIP
-        stream; rounds are dealt to whichever worker is free, so the latency-bound text / LSTM phases of one round run under the conv-bound vocoder
-        of another (bench.py's "two batches in flight": 43.8 -> 40.0 ms per B = 32 step).  A request's bits do not depend on which worker ran it."""
+        contexts: batches in flight on ONE copy of the weights: the service makes `contexts - 1` further kk_contexts of the model
+        (model.new_context(): own graph cache, side stream, workspace; the kk_model is immutable and shared).  replicas: further loaded models
+        (e.g. another device's copy).  Every context / model gets a worker thread with its own HIP stream; rounds are dealt to whichever
+        worker is free, so the latency-bound text / LSTM phases of one round run under the conv-bound vocoder of another (bench.py's "two batches
+        in flight": 43.8 -> 40.0 ms per B = 32 step).  A request's bits do not depend on which worker ran it."""
         from . import _lib
 
         self.model = model
-        self.models = [model, *replicas]
+        self.models = [model, *[model.new_context() for _ in range(max(1, int(contexts)) - 1)], *replicas]
         self.max_batch = int(max_batch)
         self.max_wait = float(max_wait_ms) / 1e3
         self.noise_mode = _lib.NOISE_PHILOX if noise_mode is None else int(noise_mode)

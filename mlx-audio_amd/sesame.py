@@ -96,6 +96,18 @@ class Model:
         self.sample_rate = 24000
         self._seed_counter = 0
 
+    def share(self) -> "Model":
+        """A second Model on the SAME device weights (kk_csm_share + Mimi.share): own KV caches, graph cache, codec workspace / streams --
+        one per job in flight (own HIP stream / host thread).  The reference's Model is single threaded."""
+        import copy
+
+        other = copy.copy(self)
+        other.model = self.model.share()
+        other._audio_tokenizer = self._audio_tokenizer.share() if self._audio_tokenizer is not None else None
+        other._streaming_decoder = None
+        other._seed_counter = 0
+        return other
+
     # ---- config / weights ------------------------------------------------------------------------------------------------------------
     def _cfg(self) -> dict:
         return csm_config_from(self.config)

@@ -450,3 +450,56 @@ def test_csm_sampler_matches_oracle_incl_tie_walls(V):
             assert rc == 0, lib.kk_last_error()
             torch.cuda.synchronize()
             np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"temp {temp} top_k {top_k}")
+
+
+def test_csm_shared_weights_two_generators_in_flight():
+    """kk_csm_share: a second generator on the SAME device weights (own KV caches, positions, logits, graphs).  Two jobs on two HIP streams and
+    two host threads, graph replay on, give the codes each gives alone; the original's caches are untouched by the other's frames."""
+    import threading
+
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_tiny_config()
+    w = P.csm_synth_checkpoint(cfg, 4)
+    rng = np.random.default_rng(15)
+    B, n = 2, cfg["audio_num_codebooks"]
+    prompts = [_prompt(cfg, rng, B, 7, 3), _prompt(cfg, rng, B, 5, 2)]
+
+    def run(model, tok, msk, frames=6):
+        model.reset_caches()
+        out = [model.generate_frame(torch.tensor(tok), torch.tensor(msk)).clone()]
+        for _ in range(frames - 1):
+            t_in = torch.zeros((B, 1, n + 1), dtype=torch.int64, device="cuda")
+            t_in[:, 0, :n] = out[-1]
+            m_in = torch.zeros((B, 1, n + 1), dtype=torch.float32, device="cuda")
+            m_in[:, 0, :n] = 1
+            out.append(model.generate_frame(t_in, m_in).clone())
+        return torch.stack(out).cpu().numpy()
+
+    a = SesameModel(cfg, w)
+    a.setup_caches(B)
+    want = [run(a, *prompts[0]), run(a, *prompts[1])]
+    b = a.share()
+    assert b._h.value != a._h.value
+    b.setup_caches(B)
+    for m in (a, b):
+        m.set_graph_mode(True)
+    got, errs = {}, []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def work(k, model):
+        try:
+            with torch.cuda.stream(streams[k]):
+                for rep in range(3):  # eager, capture, replay
+                    got[k] = run(model, *prompts[k])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(k, m)) for k, m in enumerate((a, b))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    del b  # the shared generator goes first; the weights stay with `a`
+    np.testing.assert_array_equal(run(a, *prompts[1]), want[1])

@@ -351,15 +351,19 @@ def test_graph_replay_equals_eager_bitexact(dtype):
 
 
 def test_two_batches_in_flight_equal_one_at_a_time():
-    """bench.py's default (--streams 2) and TTSService(replicas=...): consecutive batches alternate over two engine instances on two HIP streams and
-    overlap on the GPU.  Every batch still gets the bits it gets alone (graph replay and eager), whichever engine / stream ran it."""
+    """bench.py's default (--streams 2) and TTSService(contexts=2): consecutive batches alternate over TWO CONTEXTS OF ONE MODEL (one copy of the
+    weights; kk_context_create: own graph cache, side stream, workspace) on two HIP streams and overlap on the GPU.  Every batch still gets the
+    bits it gets alone (graph replay and eager), whichever context / stream ran it; a host thread per context does too."""
     from mlx_audio_amd import _lib
 
     cfg = P.tiny_config()
     w = P.synth_checkpoint(cfg, 0)
     rng = np.random.default_rng(77)
     utts = [rng.integers(1, 178, n).tolist() for n in (30, 11, 23, 5)]
-    engs = [_engine(cfg, w, "bfloat16") for _ in range(2)]
+    engs = [_engine(cfg, w, "bfloat16")]
+    engs.append(engs[0].new_context())
+    assert engs[1]._m.value == engs[0]._m.value and engs[1]._h.value != engs[0]._h.value  # one kk_model, two kk_contexts
+    assert engs[0].lib.kk_context_model(engs[1]._h) == engs[0]._m.value
     dev = engs[0].device
     ref_s = torch.tensor(_style_rows(rng, 4), device=dev)
     ids, lens, Tmax = engs[0].pack_ids(utts)
@@ -383,6 +387,27 @@ def test_two_batches_in_flight_equal_one_at_a_time():
         torch.cuda.synchronize()
         for seed in range(6):
             assert torch.equal(got[seed], want[seed]), (graph, seed)
+    # two host threads, one context each, the shared model underneath (graphs are warm: every call is a replay)
+    import threading
+
+    got, errs = {}, []
+
+    def work(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                for seed in range(k, 6, 2):
+                    engs[k].forward(ids, lens, ref_s, sp, 300, noise_mode=_lib.NOISE_PHILOX, seed=seed, out=outs[k])
+                    got[seed] = outs[k].clone()
+                streams[k].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for seed in range(6):
+        assert torch.equal(got[seed], want[seed]), ("threads", seed)
     for e in engs:
         e.set_graph_mode(False)
 
@@ -861,9 +886,9 @@ def test_tts_service_concurrent_requests_equal_sequential_ones(tmp_path):
         assert a.segments == b.segments == len(t.split("\n")) and a.phonemes == b.phonemes == t.split("\n")
         assert a.audio.dtype == np.float32 and a.audio.ndim == 1 and a.audio.shape[0] % 600 == 0
         np.testing.assert_array_equal(a.audio, b.audio)
-    # two models of the same checkpoint = two workers on two HIP streams: rounds overlap, every request still gets the same bits
-    model2 = Model(ModelConfig.from_dict(dict(cfg, model_type="kokoro")), weights=P.synth_checkpoint(cfg, 0))
-    with TTSService(model, max_batch=4, max_wait_ms=0.0, replicas=[model2], **kw) as svc2:
+    # two contexts of the ONE loaded model = two workers on two HIP streams: rounds overlap, every request still gets the same bits
+    with TTSService(model, max_batch=4, max_wait_ms=0.0, contexts=2, **kw) as svc2:
+        assert len(svc2.models) == 2 and svc2.models[1].engine._m.value == model.engine._m.value
         futs2 = [svc2.submit(texts[i % len(texts)], voice=voices[i % 2], speed=speeds[i % len(texts)], language="e") for i in range(3 * len(texts))]
         two = [f.result(timeout=120) for f in futs2]
     assert svc2.stats["requests"] == 3 * len(texts)

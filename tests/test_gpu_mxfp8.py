@@ -167,7 +167,7 @@ def test_quantised_model_runs_fp8_and_tracks_the_oracle():
     pack = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "af_heart_rows.npz"))["rows"]
     ref_s = pack[rng.integers(0, pack.shape[0], 2)].astype(np.float32)
     eng = KokoroEngine(cfg, w, compute_dtype="bfloat16", quantization={"group_size": 64, "bits": 8})
-    assert eng.lib.kk_quantized_layers(eng._h) == 6
+    assert eng.quantized_layers() == 6
     dev = eng.device
     ids, lens, Tmax = eng.pack_ids(utts)
     durs = np.zeros((2, Tmax), np.int32)
@@ -236,7 +236,7 @@ def test_load_model_on_an_8bit_checkpoint_exact_default_and_fp8_opt_in(tmp_path)
     ps = "hɛlˈoʊ wˈɜɹld"
     ref_s = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "af_heart_rows.npz"))["rows"][3][None]  # any real style row
     exact = load_model(str(d), compute_dtype="bfloat16")  # default: exact semantics
-    assert exact.engine.lib.kk_quantized_layers(exact.engine._h) == 0
+    assert exact.engine.quantized_layers() == 0
     oe = exact(ps, ref_s, 1.0, return_output=True)
     orc = O.KokoroOracle(dequantize_checkpoint(wq, 64, 8), {k: v for k, v in cfg.items() if k != "vocab"})
     want = orc.text_stage(exact._ids(ps), ref_s, 1.0)
@@ -247,7 +247,7 @@ def test_load_model_on_an_8bit_checkpoint_exact_default_and_fp8_opt_in(tmp_path)
     with pytest.raises(ValueError):
         load_model(str(d), quantization_kernel="int4")
     model = load_model(str(d), compute_dtype="bfloat16", quantization_kernel="mxfp8")
-    assert model.engine.lib.kk_quantized_layers(model.engine._h) == 6
+    assert model.engine.quantized_layers() == 6
     out = model(ps, ref_s, 1.0, return_output=True)
     assert torch.isfinite(out.audio).all() and out.audio.shape[1] == 600 * int(out.pred_dur.sum())
     direct = KokoroEngine({k: v for k, v in cfg.items() if k != "vocab"}, dequantize_checkpoint(wq, 64, 8), compute_dtype="bfloat16",
@@ -256,4 +256,4 @@ def test_load_model_on_an_8bit_checkpoint_exact_default_and_fp8_opt_in(tmp_path)
     pred = direct.forward_text(ids, lens, torch.tensor(ref_s, device=direct.device), torch.ones(1, device=direct.device))
     np.testing.assert_array_equal(pred.cpu().numpy()[0, : int(lens[0])], out.pred_dur.cpu().numpy())
     m32 = load_model(str(d), compute_dtype="float32")  # the exact path never quantises
-    assert m32.engine.lib.kk_quantized_layers(m32.engine._h) == 0
+    assert m32.engine.quantized_layers() == 0

@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "kokoro_hip.h")).read()
     declared = set(re.findall(r"\b(kk_[a-z0-9_]+)\s*\(", hdr))
     lib = _lib.load()
-    assert lib.kk_abi_version() == 1
+    assert lib.kk_abi_version() == 2
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in kokoro_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
