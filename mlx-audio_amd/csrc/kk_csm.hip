@@ -78,6 +78,10 @@ struct kk_csm {
   bool graph_mode = false;
   std::vector<GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;
+  // kk_csm_reset_caches / kk_csm_set_padding take no stream: what they change on the device is applied on the NEXT frame's stream (a
+  // synchronous hipMemset / hipMemcpy here would touch the legacy stream and break another thread's graph capture)
+  bool reset_pending = false, pad_pending = false;
+  std::vector<int32_t> pad_host;
   const kk_csm* weights_of = nullptr;  // kk_csm_share: `dev` / `devb` belong to that generator (immutable after finalize), not to this one
 };
 
@@ -1454,6 +1458,8 @@ extern "C" int kk_csm_share(const kk_csm* m, kk_csm** out) {
   c->max_batch = 0;
   c->dbg_logits = nullptr;
   c->graphs.clear();
+  c->reset_pending = c->pad_pending = false;
+  c->pad_host.clear();
   c->cap_stream = nullptr;
   *out = c;
   return 0;
@@ -1566,6 +1572,7 @@ extern "C" int kk_csm_setup_caches(kk_csm* m, int max_batch) {
   if (hipMalloc((void**)&m->bb.pad_dev, (size_t)max_batch * 4) != hipSuccess || hipMemset(m->bb.pad_dev, 0, (size_t)max_batch * 4) != hipSuccess)
     return kk_fail("kk_csm_setup_caches: hipMalloc failed");
   m->max_batch = max_batch;
+  m->reset_pending = m->pad_pending = false;  // freshly zeroed above
   return 0;
 }
 // Ragged prompts: the streams of a batch are LEFT-padded to the longest prompt (padding frames carry an all-zero mask); pad[b] = number of
@@ -1576,15 +1583,17 @@ extern "C" int kk_csm_set_padding(kk_csm* m, int B, const int32_t* pad_host) {
   if (m->bb.offset != 0) return kk_fail("kk_csm_set_padding: the cache is not empty");
   for (int b = 0; b < B; ++b)
     if (pad_host[b] < 0 || pad_host[b] >= m->bb.max_pos) return kk_fail("kk_csm_set_padding: padding out of range");
-  if (hipMemcpy(m->bb.pad_dev, pad_host, (size_t)B * 4, hipMemcpyHostToDevice) != hipSuccess) return kk_fail("kk_csm_set_padding: copy failed");
+  m->pad_host.assign((size_t)m->max_batch, 0);
+  for (int b = 0; b < B; ++b) m->pad_host[b] = pad_host[b];
+  m->pad_pending = true;  // uploaded on the next frame's stream
   return 0;
 }
 extern "C" int kk_csm_reset_caches(kk_csm* m) {
   if (!m) return kk_fail("kk_csm_reset_caches: null model");
   m->bb.offset = 0;
   m->dec.offset = 0;
-  if (m->bb.pos_dev && hipMemset(m->bb.pos_dev, 0, 4) != hipSuccess) return kk_fail("kk_csm_reset_caches: memset failed");
-  if (m->bb.pad_dev && hipMemset(m->bb.pad_dev, 0, (size_t)m->max_batch * 4) != hipSuccess) return kk_fail("kk_csm_reset_caches: memset failed");
+  m->reset_pending = true;  // position counter and padding are cleared on the next frame's stream
+  m->pad_pending = false;
   return 0;
 }
 extern "C" int kk_csm_position(const kk_csm* m) { return m ? m->bb.offset : -1; }
@@ -1604,6 +1613,17 @@ extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, cons
   if (m->bb.offset + S > m->bb.max_pos) return kk_fail("kk_csm_generate_frame: sequence exceeds max_seq_len");
   if (S > 1 && m->bb.offset != 0) return kk_fail("kk_csm_generate_frame: a multi-token block must start an empty cache (sesame.py:41-48)");
   if (workspace_bytes < kk_csm_workspace_bytes(m, B, S)) return kk_fail("kk_csm_generate_frame: workspace too small");
+  if (m->reset_pending) {  // deferred kk_csm_reset_caches, in stream order before this frame (never inside a capture)
+    if (hipMemsetAsync(m->bb.pos_dev, 0, 4, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(m->bb.pad_dev, 0, (size_t)m->max_batch * 4, (hipStream_t)stream) != hipSuccess)
+      return kk_fail("kk_csm_generate_frame: cache reset failed");
+    m->reset_pending = false;
+  }
+  if (m->pad_pending) {  // deferred kk_csm_set_padding
+    if (hipMemcpyAsync(m->bb.pad_dev, m->pad_host.data(), (size_t)m->max_batch * 4, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+      return kk_fail("kk_csm_generate_frame: padding upload failed");
+    m->pad_pending = false;
+  }
   auto eager = [&](void* on_stream) -> int {
     Run r{m, (hipStream_t)on_stream, B, (char*)workspace, workspace_bytes, 0, false, false};
     return run_frame(r, S, tokens, tokens_mask, temperature, top_k, uniforms, codes_out);

@@ -166,13 +166,15 @@ class Mimi:
         largest step, fixed when the stream is created: the first call's F, or `max_chunk`.  A fresh (or reset) stream is re-created when the
         batch or the step outgrows it; a stream that has consumed frames cannot grow -- that is an error, never a silent restart."""
         st = self._streams.get(slot)
-        if st is not None and (st["maxb"] < B or st["maxchunk"] < chunk):
-            if int(self.lib.kk_mimi_stream_frames(st["h"])) > 0:
+        if st is not None:
+            fresh = int(self.lib.kk_mimi_stream_frames(st["h"])) == 0
+            if (st["maxb"] < B or st["maxchunk"] < chunk) and not fresh:
                 what = f"batch {B} > {st['maxb']}" if st["maxb"] < B else f"{chunk} frames per step > {st['maxchunk']}"
                 raise ValueError(f"Mimi stream: {what} on a stream that has already consumed frames; open it with max_batch= / max_chunk= large "
                                  "enough for every step, or call reset_stream() first")
-            self._close_slot(slot)
-            st = None
+            if fresh and (st["maxb"] < max(B, max_batch) or st["maxchunk"] < max(chunk, max_chunk)):  # a fresh / reset stream may be re-sized
+                self._close_slot(slot)
+                st = None
         if st is None:
             h = C.c_void_p()
             mb, mc = max(B, max_batch), max(chunk, max_chunk)

@@ -833,6 +833,16 @@ def test_pipeline_batch_scheduler_matches_chunk_by_chunk(tmp_path):
     for a, b in zip(seq, bat):
         np.testing.assert_array_equal(a.pred_dur.cpu().numpy(), b.pred_dur.cpu().numpy())
         assert a.audio.shape == b.audio.shape and torch.isfinite(b.audio).all()
+    # the product multi-GPU entry at world size 1 (no collective) IS the batched pipeline: same plan, same seeds, same bits
+    from mlx_audio_amd.parallel import ShardedSynth
+
+    model._seed = 100
+    bat = list(pipe("\n".join(lines), voice=str(tmp_path / "voice.npy"), batch_size=4))
+    model._seed = 100
+    sh = ShardedSynth(pipe, dist=None, batch_size=4)("\n".join(lines), voice=str(tmp_path / "voice.npy"))
+    assert [r.phonemes for r in sh] == lines and [r.text_index for r in sh] == [r.text_index for r in bat]
+    for a, b in zip(bat, sh):
+        assert torch.equal(a.audio, b.audio) and torch.equal(a.pred_dur, b.pred_dur)
 
 
 def test_tts_service_concurrent_requests_equal_sequential_ones(tmp_path):

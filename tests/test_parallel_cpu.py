@@ -141,3 +141,100 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and '"n_gpus": 1' in r.stdout
+
+
+# ---- the product entry: ShardedSynth with a stub model that returns a deterministic waveform per chunk ------------------------------
+class _StubModel:
+    """batch_call of kokoro.Model, no GPU: chunk `ps` with style row r -> 600 * len(ps) samples = f(ps, r[0], position), durations 1..T."""
+
+    def __init__(self):
+        self.calls = []
+
+    def batch_call(self, phonemes, ref_s, speed=1, seed=None):
+        from mlx_audio_amd.kokoro import Model
+
+        self.calls.append(list(phonemes))
+        out = []
+        for p, r in zip(phonemes, ref_s):
+            n = 600 * len(p)
+            wav = (torch.arange(n, dtype=torch.float32) * 1e-3 + float(sum(map(ord, p)) % 97) + float(r[0])).reshape(1, n)
+            out.append(Model.Output(audio=wav, pred_dur=torch.arange(1, len(p) + 3, dtype=torch.int32)))
+        return out
+
+    def __call__(self, ps, ref_s, speed=1, return_output=False):
+        return self.batch_call([ps], np.asarray(ref_s).reshape(1, 256), speed)[0]
+
+
+def _stub_pipeline():
+    from mlx_audio_amd.pipeline import KokoroPipeline
+
+    p = KokoroPipeline(lang_code="e", model=_StubModel(), repo_id="m", g2p=lambda t: (t, None))  # identity G2P, non-English branch
+    p.voices["v"] = np.repeat(np.arange(510, dtype=np.float32)[:, None, None], 256, axis=2)
+    return p
+
+
+_TEXT = "\n".join("abcdefghij"[: 1 + (7 * i) % 10] * (1 + (5 * i) % 9) for i in range(23))
+
+
+def _expected():
+    """The plain single-process pipeline, chunk by chunk."""
+    p = _stub_pipeline()
+    return [(r.text_index, r.phonemes, np.asarray(r.audio).reshape(-1)) for r in p(_TEXT, voice="v")]
+
+
+def test_sharded_synth_world1_equals_the_plain_pipeline():
+    exp = _expected()
+    p = _stub_pipeline()
+    got = par.ShardedSynth(p, dist=None, batch_size=4)(_TEXT, voice="v")
+    assert [(r.text_index, r.phonemes) for r in got] == [(a, b) for a, b, _ in exp]
+    for r, (_, _, w) in zip(got, exp):
+        np.testing.assert_array_equal(np.asarray(r.audio).reshape(-1), w)
+    assert max(len(c) for c in p.model.calls) <= 4 and sum(len(c) for c in p.model.calls) == len(exp)
+
+
+def _synth_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = _stub_pipeline()
+        synth = par.ShardedSynth(p, dist=dist, batch_size=4, device=torch.device("cpu"))
+        res = synth(_TEXT if rank == 0 else "ignored on this rank", voice="v")
+        mine = synth.last_assignment[rank]
+        ran = sorted(ps for c in p.model.calls for ps in c)
+        if rank == 0:
+            q.put((rank, [(r.text_index, r.phonemes, np.asarray(r.audio).reshape(-1), np.asarray(r.pred_dur)) for r in res], synth.last_assignment, ran))
+        else:
+            q.put((rank, res, mine, ran))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_synth_world2_gloo():
+    """Rank 0 plans the chunks, both ranks synthesise their balanced share, rank 0 gets every waveform and duration vector back in TEXT order;
+    the other rank returns None and ran only its own chunks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_synth_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in ps:
+        item = q.get(timeout=180)
+        got[item[0]] = item[1:]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = _expected()
+    res, assign, ran0 = got[0]
+    assert got[1][0] is None
+    assert [(a, b) for a, b, _, _ in res] == [(a, b) for a, b, _ in exp]
+    for (_, ps_, w, d), (_, _, we) in zip(res, exp):
+        np.testing.assert_array_equal(w, we)
+        np.testing.assert_array_equal(d, np.arange(1, len(ps_) + 3))
+    # the work was really split, and balanced by predicted frames
+    assert sorted(assign[0] + assign[1]) == list(range(len(exp))) and assign[0] and assign[1]
+    loads = [sum(len(exp[i][1]) for i in g) for g in assign]
+    assert abs(loads[0] - loads[1]) <= max(len(e[1]) for e in exp)
+    assert ran0 == sorted(exp[i][1] for i in assign[0]) and got[1][2] == sorted(exp[i][1] for i in assign[1])
