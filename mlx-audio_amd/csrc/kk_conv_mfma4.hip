@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, B0), b1 = __builtin_bit_cast(bf16x8, B1);                     \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                          \
           const bf16x8 av = *(const bf16x8*)(xa + mi * 32 * XLD + (KS) * 16);                                       \
-          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[mi][0], 0, 0, 0);                         \
-          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[mi][1], 0, 0, 0);                         \
+          acc[mi][0] = kk_mfma32<(KS)>(av, b0, acc[mi][0]);                         \
+          acc[mi][1] = kk_mfma32<(KS)>(av, b1, acc[mi][1]);                         \
         }                                                                                                            \
         B0 = fn[(KS) * 64];       /* the registers are free as soon as these MFMAs are issued */                   \
         B1 = fn[(4 + (KS)) * 64];                                                                                   \
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_wave
         for (int ks = 0; ks < CK / 16; ++ks) {
 #pragma unroll
           for (int j = 0; j < MI; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, KK_MFMA_PER, 0);
             if (ks < CK / 16 - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MI * KK_MFMA_PER, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
       }
