@@ -76,6 +76,9 @@ if __name__ == "__main__":
     if "--trace" in sys.argv:  # phase-timing build of the MFMA conv kernel, loaded with KK_HIP_LIB=<path>
         build(force="--force" in sys.argv, extra_flags=("-DKK_MFMA_TRACE",), out=os.path.join(HERE, "libkokoro_hip_trace.so"),
               obj_dir=os.path.join(CSRC, "_obj_trace"))
+    elif "--mfma32" in sys.argv:  # A/B build: the round-2 32x32x16 MFMA shape in conv variants 4 / 5 (kk_conv_mfma_shared.h)
+        build(force="--force" in sys.argv, extra_flags=("-DKK_MFMA32",), out=os.path.join(HERE, "libkokoro_hip_mfma32.so"),
+              obj_dir=os.path.join(CSRC, "_obj_mfma32"))
     elif "--exp16" in sys.argv:  # TIMING-ONLY experiment build (wrong conv results): kk_conv_mfma_shared.h, KK_EXP_MFMA16
         build(force="--force" in sys.argv, extra_flags=("-DKK_EXP_MFMA16",), out=os.path.join(HERE, "libkokoro_hip_exp16.so"),
               obj_dir=os.path.join(CSRC, "_obj_exp16"))

@@ -54,9 +54,10 @@ namespace {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128, CK = 64, BM = 192, WM = 96, MI = 3;
-constexpr int XLD = CK + 8;   // elements per LDS row (144 B: conflict-free ds_read_b128 fragments)
+constexpr int BN = 128, CK = 64, BM = 192, WM = 96, MI = 3, MI16 = WM / 16;
+constexpr int XLD = KK_XLD;   // elements per LDS row (160 B / 144 B: conflict-free ds_read_b128 fragments of the 16- / 32-row MFMA shape, kk_conv_mfma4.hip)
 constexpr int MAX_HALO = 50;  // (Kw-1)*dil of the largest resblock conv (k 11, dilation 5)
 constexpr int CLD = BN;       // fp32 C tile pitch
 constexpr int XROWS = BM + MAX_HALO;
@@ -145,6 +146,13 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
   if (mfma_role) {
     // ============================================================ MFMA waves
     const int wr = wave >> 1, wc = wave & 1;
+#ifdef KK_MFMA16
+    f32x4 acc[MI16][4];
+#pragma unroll
+    for (int i = 0; i < MI16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -152,7 +160,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // pack order of the weights: [tap][n block][chunk][wc][ni][ks][lane] x 16 bytes
+#endif
+    // pack order of the weights: [tap][n block][chunk][wc][ks][ni][lane] x 16 bytes (kk_mfma4_pack_index; [wc][ni][ks] with -DKK_MFMA32)
     const uint4* wbase = (const uint4*)a.wf + (wc * 2) * 4 * 64 + lane;
     // The B fragments of iteration it + 2 are requested right behind the MFMAs of iteration it (two named register sets, even / odd it;
     // nit is even): with ONE MFMA wave per SIMD nothing else hides the L2 latency of a weight load -- one iteration ahead (variant 4's
@@ -175,12 +184,54 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
         }
       }
     };
+#ifdef KK_MFMA16
+    const int arow = wr * WM + (lane & 15);
+    const int kofs = 8 * (lane >> 4);
+#else
     const int arow = wr * WM + (lane & 31);
     const int kofs = 8 * (lane >> 5);
+#endif
     KK_BAR5();  // [P] slab 0 of the first tile is in LDS (and s_lout is written)
     if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);  // beside a service wave on the same SIMD, the MFMA wave's LDS reads / weight loads issue first
     const unsigned long long trm0 = TR5_NOW();
     (void)trm0;
+#ifdef KK_MFMA16
+#define KK_KSTEP5(KS, B0, B1, B2, B3)                                                                           \
+    {                                                                                                            \
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, B0), b1 = __builtin_bit_cast(bf16x8, B1);                   \
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, B2), b3 = __builtin_bit_cast(bf16x8, B3);                   \
+      _Pragma("unroll") for (int mi = 0; mi < MI16; ++mi) {                                                      \
+        const bf16x8 av = *(const bf16x8*)(xa + mi * 16 * XLD + (KS) * 32);                                     \
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[mi][0], 0, 0, 0);                       \
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[mi][1], 0, 0, 0);                       \
+        acc[mi][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2, acc[mi][2], 0, 0, 0);                       \
+        acc[mi][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b3, acc[mi][3], 0, 0, 0);                       \
+      }                                                                                                          \
+      B0 = fn[((KS) * 4 + 0) * 64];                                                                              \
+      B1 = fn[((KS) * 4 + 1) * 64];                                                                              \
+      B2 = fn[((KS) * 4 + 2) * 64];                                                                              \
+      B3 = fn[((KS) * 4 + 3) * 64];                                                                              \
+    }
+#define KK_STEPS5(Q00, Q01, Q02, Q03, Q10, Q11, Q12, Q13)                                                       \
+      KK_KSTEP5(0, Q00, Q01, Q02, Q03)                                                                           \
+      KK_KSTEP5(1, Q10, Q11, Q12, Q13)                                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                         \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+        _Pragma("unroll") for (int j = 0; j < MI16; ++j) {                                                       \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                     \
+          if (ks * MI16 + j + 2 < 2 * MI16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                       \
+      }
+#define KK_CDUMP5()                                                                                              \
+          _Pragma("unroll") for (int mi = 0; mi < MI16; ++mi)                                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                                   \
+              const int col = wc * 64 + ni * 16 + (lane & 15);                                                   \
+              const int rbase = wr * WM + mi * 16 + 4 * (lane >> 4);                                             \
+              _Pragma("unroll") for (int r = 0; r < 4; ++r) Cs[(rbase + r) * CLD + col] = acc[mi][ni][r];       \
+              acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
+            }
+#else
 #define KK_KSTEP5(KS, B0, B1)                                                                                   \
     {                                                                                                            \
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, B0), b1 = __builtin_bit_cast(bf16x8, B1);                   \
@@ -192,23 +243,36 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
       B0 = fn[(KS) * 64];                                                                                        \
       B1 = fn[(4 + (KS)) * 64];                                                                                 \
     }
+#define KK_STEPS5(Q00, Q01, Q02, Q03, Q10, Q11, Q12, Q13)                                                       \
+      KK_KSTEP5(0, Q00, Q10)                                                                                     \
+      KK_KSTEP5(1, Q01, Q11)                                                                                     \
+      KK_KSTEP5(2, Q02, Q12)                                                                                     \
+      KK_KSTEP5(3, Q03, Q13)                                                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < CK / 16; ++ks) {                                                   \
+        _Pragma("unroll") for (int j = 0; j < MI; ++j) {                                                         \
+          __builtin_amdgcn_sched_group_barrier(0x008, KK_MFMA_PER, 0);                                           \
+          if (ks < CK / 16 - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * KK_MFMA_PER, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                       \
+      }
+#define KK_CDUMP5()                                                                                              \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                      \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                   \
+              const int col = wc * 64 + ni * 32 + (lane & 31);                                                   \
+              const int rbase = wr * WM + mi * 32 + 4 * (lane >> 5);                                             \
+              _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+                Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];                               \
+                acc[mi][ni][r] = 0.f;                                                                            \
+              }                                                                                                  \
+            }
+#endif
 #define KK_ITER5(Q00, Q01, Q02, Q03, Q10, Q11, Q12, Q13)                                                                                  \
     {                                                                                                                                     \
       const uint4* fn = cursor();                                                                                                         \
       const bf16_t* xa = Xs + (arow + tap * dstep) * XLD + kofs; /* row shift of this tap inside the slab */                              \
-      KK_KSTEP5(0, Q00, Q10)                                                                                                              \
-      KK_KSTEP5(1, Q01, Q11)                                                                                                              \
-      KK_KSTEP5(2, Q02, Q12)                                                                                                              \
-      KK_KSTEP5(3, Q03, Q13)                                                                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);                                                                                 \
-      _Pragma("unroll") for (int ks = 0; ks < CK / 16; ++ks) {                                                                            \
-        _Pragma("unroll") for (int j = 0; j < MI; ++j) {                                                                                  \
-          __builtin_amdgcn_sched_group_barrier(0x008, KK_MFMA_PER, 0);                                                                              \
-          if (ks < CK / 16 - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                        \
-        }                                                                                                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * KK_MFMA_PER, 0);                                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                                                \
-      }                                                                                                                                   \
+      KK_STEPS5(Q00, Q01, Q02, Q03, Q10, Q11, Q12, Q13)                                                                                  \
       asm volatile("" ::: "memory");                                                                                                      \
       advance();                                                                                                                          \
       if (++tap == ntaps) {                                                                                                               \
@@ -220,15 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
         (void)ta0; (void)ta1;                                                                                                             \
         if (++chunk == nchunk) { /* the finished tile -> C buffer (the service waves finished the previous tile's C before [A]) */        \
           chunk = 0;                                                                                                                      \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                               \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                                            \
-              const int col = wc * 64 + ni * 32 + (lane & 31);                                                                            \
-              const int rbase = wr * WM + mi * 32 + 4 * (lane >> 5);                                                                      \
-              _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                            \
-                Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];                                                        \
-                acc[mi][ni][r] = 0.f;                                                                                                     \
-              }                                                                                                                           \
-            }                                                                                                                             \
+          KK_CDUMP5()                                                                                                                     \
         }                                                                                                                                 \
         KK_BAR5(); /* [B] next slab in LDS (and, after a tile's last slab, its C complete) */                                             \
         TR5_ADD(2, TR5_NOW() - ta1);                                                                                                      \
@@ -268,6 +324,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
     }
 #undef KK_ITER5
 #undef KK_KSTEP5
+#undef KK_STEPS5
+#undef KK_CDUMP5
     TR5_ADD(0, TR5_NOW() - trm0);
     if (a.stat_part) KK_BAR5();  // (the service waves' last statistics reduction has one more barrier: keep the counts equal)
     return;

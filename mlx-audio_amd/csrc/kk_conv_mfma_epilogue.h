@@ -40,6 +40,18 @@
       if (pass > 0) __syncthreads();  // previous pass's readers are done with Cs
       // rows [RPP*pass, RPP*pass + RPP) of the block tile: tall tiles -> wave row `pass`; 128-row tile -> both wave rows
       if (wr == pass) {
+#ifdef KK_EPI_ACC16
+        // 16 x 16 blocks (v_mfma_f32_16x16x32_bf16): lane l holds rows 4 * (l / 16) .. + 3 of column l % 16
+#pragma unroll
+        for (int mi = 0; mi < WM / 16; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int col = wc * 64 + ni * 16 + (lane & 15);
+            const int rbase = mi * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(rbase + r) * CLD + col] = acc[mi][ni][r];
+          }
+#else
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -49,6 +61,7 @@
 #pragma unroll
             for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CLD + col] = acc[mi][ni][r];
           }
+#endif
       }
       __syncthreads();
     }

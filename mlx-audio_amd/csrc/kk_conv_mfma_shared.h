@@ -2,6 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Matrix-instruction shape of variants 4 / 5: v_mfma_f32_16x16x32_bf16 (default) or, with -DKK_MFMA32, the round-2 v_mfma_f32_32x32x16_bf16.
+// KK_XLD = elements per LDS row of the X slab: 160 B keeps the 16-row fragments' ds_read_b128 conflict-free (see kk_conv_mfma4.hip), 144 B the 32-row ones.
+#if !defined(KK_MFMA32) && !defined(KK_EXP_MFMA16)
+#define KK_MFMA16 1
+#endif
+#ifdef KK_MFMA16
+#define KK_XLD 80
+#else
+#define KK_XLD 72
+#endif
+
 namespace {
 // Two floats WITHOUT the packed-f32 instructions (v_pk_fma_f32 ...): beside another wave's MFMAs on the same SIMD the packed forms run at
 // about half rate (variant 5's service waves showed it first; 2-6 % per fused launch of variant 4).  The files that include this are built
