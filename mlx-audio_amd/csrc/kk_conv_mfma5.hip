@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
     asm volatile("" ::: "memory");
   };
   // the fused input transform, in registers (the slab is stored later, between the two barriers)
-  auto transform_x = [&](int chunk, uint4 (&xreg)[XREG], const unsigned xok) __attribute__((always_inline)) {
+  auto transform_x = [&](int chunk, uint4 (&xreg)[XREG], const unsigned xok, const bool nomask) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < XREG; ++i) asm volatile("" : "+v"(xreg[i].x), "+v"(xreg[i].y), "+v"(xreg[i].z), "+v"(xreg[i].w));
     if (NRM) {
@@ -407,7 +407,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
         }
       }
     }
-    // padding rows / pad channels stay exactly zero (32-bit integer ops only, see variant 4)
+    // padding rows / pad channels stay exactly zero (32-bit integer ops only, see variant 4).  A fused slab that lies inside the utterance and
+    // inside the real channels (uniform over the workgroup: `nomask`) has nothing to mask -- all but the edge tiles -- and skips the ANDs.
+    if (NRM != 0 && nomask) return;
     const int cfirst = chunk * CK + (stid & 7) * 8;
     unsigned cm[4];
 #pragma unroll
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
 #pragma unroll
     for (int k = 0; k < 4; ++k) bias2[k] = v2f{s_bias[n + 2 * k], s_bias[n + 2 * k + 1]};
     const v2f scale2 = {a.scale, a.scale}, act_slope2 = {a.act_slope, a.act_slope};
+    const bool tile_full = t.live && t.q0 + BM <= t.Lout && t.q0 + BM <= a.Q && t.q0 + BM <= a.Lo_rows && t.n0 + BN <= a.Cout;  // uniform
     // C rows one task ahead (the read of task i + 1 is in flight while task i is computed); unconditional, a dead tile's are not used
     const float* crow = Cs + (tbase * 16 + (stid >> 4)) * CLD + (stid & 15) * 8;
     float4 cn0 = *(const float4*)crow, cn1 = *(const float4*)(crow + 4);
@@ -529,31 +532,36 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
       }
+      if (a.scale != 1.0f) {  // (uniform; 1 everywhere but the mean over the three resblocks)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] *= scale2;
+        for (int k = 0; k < 4; ++k) v[k] *= scale2;
+      }
       if (ACC) {
         const unsigned w4[4] = {rold[i].x, rold[i].y, rold[i].z, rold[i].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
       }
-      const unsigned lm = lv ? 0xFFFFFFFFu : 0u;  // rows past the utterance are stored as exact zeros
+      // rows past the utterance are stored as exact zeros (and count as zeros in the statistics); only a tile that reaches past its
+      // utterance pays the selects (tile_full is uniform)
+      if (!tile_full && !(lv && wr_ok)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
+      }
       unsigned w4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bf16x2 pk = {(bf16_t)v[k].x, (bf16_t)v[k].y};
-        w4[k] = __builtin_bit_cast(unsigned, pk) & lm;
+        w4[k] = __builtin_bit_cast(unsigned, pk);
       }
       // The store is UNCONDITIONAL (lanes outside the output write their own slot of a dump area): stores retire through the same
       // in-order counter as loads, and a store hipcc cannot count makes the next wait for a load drain the row requests behind it.
       uint4* dst = wr_ok ? (uint4*)(ob + (long long)opc * a.ldo + n) : dump;
       *dst = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-      if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
-        const unsigned sm = wr_ok ? 0xFFFFFFFFu : 0u;
+      if (a.stat_part) {  // column statistics from the fp32 values before the bf16 rounding (see kk_conv_mfma_epilogue.h)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const v2f r = {__uint_as_float((w4[k] & sm) << 16), __uint_as_float(w4[k] & sm & 0xFFFF0000u)};
-          st_s[k] += r;
-          st_q[k] = fma2(r, r, st_q[k]);
+          st_s[k] += v[k];
+          st_q[k] = fma2(v[k], v[k], st_q[k]);
         }
       }
       asm volatile("" ::: "memory");  // one task at a time (plus the C rows read ahead): hoisting every task's reads costs ~50 registers
@@ -597,12 +605,17 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
     }
   };
 
+  // nothing to mask in a staged slab: its rows [q0 + off0, q0 + off0 + xrows) lie inside the utterance and its 64 channels are real (uniform)
+  auto slab_inside = [&](const Item& t, int chunk) __attribute__((always_inline)) -> bool {
+    const int r0 = t.q0 + off0, r1 = t.q0 + off0 + xrows - 1;
+    return r0 >= 0 && (a.in_shift ? (r1 >> a.in_shift) : r1) < t.Lin && chunk * CK + CK <= cin_real;
+  };
   // ---- prologue: slab 0 of the first tile into LDS, slab 1 requested
   Item cur = decode(v);
   if (cur.live) {
     load_x(cur, 0, xr0, xk0);
     load_params(cur, 0);
-    transform_x(0, xr0, xk0);
+    transform_x(0, xr0, xk0, slab_inside(cur, 0));
     store_x(xr0);
     load_x(cur, 1, xr1, xk1);
   }
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
       if (tail && a.stat_part) stats_to_lds();
     }
     const unsigned long long t2 = TR5_NOW();
-    if (stage1 && !(a.dbg & 8)) transform_x(c1, XT, xkT);
+    if (stage1 && !(a.dbg & 8)) transform_x(c1, XT, xkT, slab_inside(s1, c1));
     // request the residual rows of the NEXT period's epilogue share: of `prev` inside a tile, of `cur` (the next `prev`) at its end
     {
       const int tb = tail ? 0 : (c + 1 >= act0 ? (c + 1 - act0) * TPP : 0);

@@ -10,6 +10,8 @@
   const int nc = n < a.Cout ? n : 0;  // clamped for the unconditional loads
   const int lo_hi = a.Lo_rows - 1;
   constexpr int VEC = sizeof(TO) == 2 ? 1 : 2;  // 16-byte vectors per 8 outputs
+  // every row of the tile lies inside the utterance (uniform; true for all but the last tile of an utterance)
+  const bool tile_full = tile_live && !a.flat_T && (a.mode == KK_CONV ? q0 + BM - 1 : phase + a.stride * (q0 + BM - 1)) < Lout;
   v2f bias2[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)  // bias has CoutP entries
@@ -79,6 +81,10 @@
         opv[i] = op < 0 ? 0 : (op > lo_hi ? lo_hi : op);
         wr_ok[i] = q < a.Q && op < a.Lo_rows && n < a.Cout;
         live[i] = tile_live && op < Lout;
+        if (a.flat_T) {  // (uniform) flat rows: the item this row belongs to decides
+          const int bb = opv[i] / a.flat_T;
+          live[i] = live[i] && (opv[i] - bb * a.flat_T) < kk_len(a.flat_len, bb);
+        }
       }
       if (rb) {  // wave-uniform
 #pragma unroll
@@ -145,8 +151,10 @@
             for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
           }
         }
+        if (a.scale != 1.0f) {  // (uniform; 1 everywhere but the mean over the three resblocks)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= scale2;
+          for (int k = 0; k < 4; ++k) v[k] *= scale2;
+        }
         if (a.accumulate) {
           if (sizeof(TO) == 2) {
             const unsigned w4[4] = {rold[i][0].x, rold[i][0].y, rold[i][0].z, rold[i][0].w};
@@ -161,21 +169,27 @@
           }
         }
         if (sizeof(TO) == 2) {
-          const unsigned lm = live[i] ? 0xFFFFFFFFu : 0u;  // rows past the utterance are stored as exact zeros
+          // rows past the utterance are stored as exact zeros; only a tile that reaches past it pays the selects (tile_full is uniform)
+          if (!tile_full && !live[i]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v2f{0.f, 0.f};
+          }
           unsigned w4[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const bf16x2 pk = {(bf16_t)v[k].x, (bf16_t)v[k].y};
-            w4[k] = __builtin_bit_cast(unsigned, pk) & lm;
+            w4[k] = __builtin_bit_cast(unsigned, pk);
           }
           if (wr_ok[i]) {
             *(uint4*)(ob + (long long)opv[i] * a.ldo + n) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            if (a.stat_part) {  // statistics of what the consumer will read (the bf16-rounded values)
+            if (a.stat_part) {
+              // column statistics for the next instance norm, from the fp32 values BEFORE the bf16 rounding (round 3: the consumer reads the
+              // rounded tensor, whose sums differ from these by the rounding noise averaged over the rows, ~1e-5 relative; the fp32 oracle
+              // normalises unrounded values too; re-widening the packed words cost 2 of the 8 VALU instructions per element pair here)
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
-                const v2f r = {__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
-                st_s[k] += r;
-                st_q[k] = fma2(r, r, st_q[k]);
+                st_s[k] += v[k];
+                st_q[k] = fma2(v[k], v[k], st_q[k]);
               }
             }
           }

@@ -87,6 +87,20 @@
           }
         }
       }
+      // A fused slab that lies inside the utterance and inside the real channels has nothing to mask (uniform over the workgroup; all but
+      // the edge tiles): straight to LDS, without the two ANDs per word
+      if (NRM != 0) {
+        const int r0 = q0 + min_off, r1 = q0 + min_off + xrows - 1;
+        if (r0 >= 0 && (a.in_shift ? (r1 >> a.in_shift) : r1) < Lin && chunk * CK + CK <= cin_real) {
+#pragma unroll
+          for (int i = 0; i < XREG; ++i) {
+            const int id = i * 256 + tid;
+            const int r = id >> 3, c8 = (id & 7) * 8;
+            if (r < xrows) *(uint4*)(Xs + r * XLD + c8) = xreg[i];
+          }
+          return;
+        }
+      }
       // this thread's 8 channels are the same for all its rows; channels >= Cin are pad and may hold anything (NaN x 0 = NaN)
       const int cfirst = chunk * CK + (tid & 7) * 8;
       unsigned cm[4];

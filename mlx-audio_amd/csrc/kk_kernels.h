@@ -41,6 +41,11 @@ struct KKMfmaArgs {
   // fused output statistics: per-tile column sums of the STORED values, part[((b*stat_ntiles + tile)*2 + {0,1})*Cout + n]
   float* stat_part;
   int stat_ntiles;
+  // FLAT rows (variants 2 / 4, k = 1 only): the launch covers the B x flat_T rows of a dense [B][flat_T][C] tensor as ONE item (B = 1, Q = B * flat_T),
+  // so that short utterances share 192-row tiles (Albert at T = 130: 22 row tiles instead of 32); row r belongs to item r / flat_T and is
+  // stored as zeros past that item's length flat_len.  0 = off.
+  int flat_T;
+  KKLen flat_len;
 };
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase

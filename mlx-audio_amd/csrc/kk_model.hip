@@ -1001,8 +1001,25 @@ struct Ctx {
       }
       const bool v5 = v4 && cx->v5_mode != 2 && (cx->v5_mode == 1 || g.Kw >= v5_min_taps) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
                       kk_mfma5_eligible(g, out.dtype);
+      // Linear layers over short utterances (Albert, T = 130 rows per item): the rows of a dense [B][T][C] tensor as ONE flat item, so that the
+      // 192-row tiles run across utterance boundaries (32 x 130 rows = 22 tiles instead of 32).  k = 1, so rows do not interact; input rows past
+      // an utterance's length are zeros already and the epilogue stores zeros there (KKMfmaArgs::flat_T).
+      int Bl = B;
+      static int no_flat = -1;
+      if (no_flat < 0) no_flat = getenv("KK_NO_FLAT") ? 1 : 0;  // (A/B timing)
+      if (!no_flat && !v5 && B > 1 && w.Kw == 1 && o.mode == KK_CONV && o.stride == 1 && o.pad == 0 && o.dil == 1 && o.in_shift == 0 && !o.nrm_a && !o.want_stats &&
+          Q == x.rows && Q == out.rows && Q % 192 != 0 && x.bs == (long long)x.rows * x.ld && out.bs == (long long)out.rows * out.ld &&
+          (!o.res || (o.res->rows == out.rows && o.res->bs == (long long)o.res->rows * o.res->ld)) && (long long)B * Q < (1ll << 30)) {
+        g.flat_T = Q;
+        g.flat_len = lout;
+        g.Q = B * Q;
+        g.Lo_rows = B * out.rows;
+        g.lin = KKLen{nullptr, 0, B * Q};
+        g.lout = KKLen{nullptr, 0, B * Q};
+        Bl = 1;
+      }
       prof_start();
-      const int rc = v5 ? kk_launch_conv_mfma5(g, B, out.dtype, st) : v4 ? kk_launch_conv_mfma4(g, B, out.dtype, st) : kk_launch_conv_mfma(g, B, out.dtype, st);
+      const int rc = v5 ? kk_launch_conv_mfma5(g, Bl, out.dtype, st) : v4 ? kk_launch_conv_mfma4(g, Bl, out.dtype, st) : kk_launch_conv_mfma(g, Bl, out.dtype, st);
       prof_stop(1, flops, bytes);
       return rc;
     }
