@@ -85,6 +85,7 @@ union U32x8 {
 template <typename TO, int WM, int NRM>
 __global__ __launch_bounds__(256, (WM == 96 ? 2 : 3)) __attribute__((amdgpu_waves_per_eu((WM == 96 ? 2 : 3), (WM == 96 ? 2 : 3)))) void conv_mfma4_kernel(KKMfmaArgs a) {
   constexpr int BM = 2 * WM, MI = WM / 32;
+  (void)MI;
   using G = Geo<BM>;
   constexpr int XREG = G::XREG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

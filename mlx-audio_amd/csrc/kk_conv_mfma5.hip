@@ -56,7 +56,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128, CK = 64, BM = 192, WM = 96, MI = 3, MI16 = WM / 16;
+constexpr int BN = 128, CK = 64, BM = 192, WM = 96, MI16 = WM / 16;
+#ifndef KK_MFMA16
+constexpr int MI = 3;
+#endif
 constexpr int XLD = KK_XLD;   // elements per LDS row (160 B / 144 B: conflict-free ds_read_b128 fragments of the 16- / 32-row MFMA shape, kk_conv_mfma4.hip)
 constexpr int MAX_HALO = 50;  // (Kw-1)*dil of the largest resblock conv (k 11, dilation 5)
 constexpr int CLD = BN;       // fp32 C tile pitch

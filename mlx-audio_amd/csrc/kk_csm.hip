@@ -628,7 +628,6 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, i
 //   * a weight meets all rows in packed fp32 FMAs (accumulators acc[8 columns][MT / 2 row pairs]); per lane the k order is fixed by the
 //     layout, so a row's bits do not depend on its batch neighbours or on MT;
 //   * the lanes' / waves' partial sums meet in LDS in a fixed order; EPI 1 adds the residual (h += ...) in place.
-constexpr int FG_U = 4;
 struct FGArgs {
   const float* x; long long xrs;   // input row m at x + m * xrs (PRO 2: 2K floats, gate | up)
   const float* nw; float eps;      // PRO 1
@@ -655,12 +654,20 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, 
   h[e] = h0 + t;
 }
 
-template <int MT, int OCT, int PRO, int EPI>
+// 16-byte weight load that is not kept in the caches (a frame reads every matrix once; MI355X_MICROARCH.md nt-weights: -5 ... -10 % per layer)
+__device__ __forceinline__ uint4 ld_w_nt(const uint4* p) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// NPRE: weight loads a wave keeps in flight (requested BEFORE the prologue, then a ring in the main loop).  Round 2 had 8 before the prologue
+// and groups of FG_U = 4 afterwards, each group an exposed HBM round trip: 16-32 KB outstanding per CU, gate|up 33.5 MB in 16 us = 2.1 TB/s.
+template <int MT, int OCT, int PRO, int EPI, int NPRE>
 __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
   constexpr int CB = 8 * OCT, KSUB = 64 / OCT, MP = MT / 2, NQ = MT / 4, OUT = CB * 8;
   constexpr int KCH = 16384 / MT;           // k rows staged at a time: xs is 64 KB (2048 rows for 8 input rows, 1024 for 16)
   constexpr int NH = PRO == 2 ? 2 : 1;      // the gated prologue holds two values per item: two half passes
-  constexpr int NPRE = 8;                   // weight loads requested before the prologue (all of them for K <= 2048 on 8-column blocks)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xs = sm;                                   // [NQ][KCH][4]
   float* red = sm;                                  // [4 waves][KSUB][OUT] (aliases xs after the main loop)
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int L = wave + 4 * i;
-      wpre[i] = wblk[(long long)(k_lo + (L < nL0 ? L : wave % nL0) * KSUB + ksub) * OCT];
+      wpre[i] = ld_w_nt(wblk + (long long)(k_lo + (L < nL0 ? L : wave % nL0) * KSUB + ksub) * OCT);
     }
   }
   // input row m of this launch as an element offset from its base (PRO 3: an item's last row comes from the audio embedding table,
@@ -813,26 +820,30 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
         }
       }
     };
-    int Lstart = wave;
-    if (kc == k_lo) {  // the preloaded rows of the first chunk
+    // The weight stream of this wave is a RING of NPRE loads in flight (round 3): slot i holds wave load L0 + 4 i; it is refilled with load
+    // L0 + 4 (i + NPRE) right before its value is used, so NPRE x 1 KiB per wave (64 KiB per CU at NPRE = 16) stay outstanding for the whole
+    // chunk -- vmcnt retires in order, hipcc waits for exactly the oldest.  The first chunk's ring was requested before the prologue (wpre).
+    if (kc != k_lo) {
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
         const int L = wave + 4 * i;
-        fma_row(wpre[i], (L < nL ? L : wave % nL) * KSUB + ksub, L < nL ? 1.0f : 0.0f);
+        wpre[i] = ld_w_nt(wblk + (long long)(kc + (L < nL ? L : wave % nL) * KSUB + ksub) * OCT);
       }
-      Lstart = wave + 4 * NPRE;
     }
-    for (int L0 = Lstart; L0 < nL; L0 += 4 * FG_U) {
-      uint4 wv[FG_U];
-      int kl[FG_U];
+    int L0 = wave;
+    for (; L0 + 4 * NPRE < nL; L0 += 4 * NPRE) {  // every slot of this round has a successor (clamped in the last round of a ragged count)
 #pragma unroll
-      for (int i = 0; i < FG_U; ++i) {  // unconditional (clamped) loads: a load under a data-dependent branch is waited for on the spot
-        const int L = L0 + 4 * i;
-        kl[i] = (L < nL ? L : L0) * KSUB + ksub;
-        wv[i] = wblk[(long long)(kc + kl[i]) * OCT];
+      for (int i = 0; i < NPRE; ++i) {
+        const int L = L0 + 4 * i, Ln = L + 4 * NPRE;
+        const uint4 wq = wpre[i];
+        wpre[i] = ld_w_nt(wblk + (long long)(kc + (Ln < nL ? Ln : L) * KSUB + ksub) * OCT);
+        fma_row(wq, L * KSUB + ksub, 1.0f);
       }
+    }
 #pragma unroll
-      for (int i = 0; i < FG_U; ++i) fma_row(wv[i], kl[i], L0 + 4 * i < nL ? 1.0f : 0.0f);
+    for (int i = 0; i < NPRE; ++i) {  // the last ring-full: nothing left to request
+      const int L = L0 + 4 * i;
+      fma_row(wpre[i], (L < nL ? L : wave % nL) * KSUB + ksub, L < nL ? 1.0f : 0.0f);
     }
   }
   // ---- reduction over the lanes that share columns (k-sub) and the 4 waves, 8 rows per pass; output o = mloc * CB + column
@@ -1130,17 +1141,18 @@ int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t 
     }
     if (a.res) g.res = a.res + (long long)m0 * a.rrs;
     g.out = a.out + (long long)m0 * a.ors;
-#define FG_GO(MT, OCT, PRO, EPI)                                                                                                        \
+#define FG_GO1(MT, OCT, PRO, EPI, NPRE)                                                                                                 \
   do {                                                                                                                                   \
     static KKDevOnce attr;                                                                                                               \
     const size_t lds_ = (fg_lds_bytes<MT, OCT>());                                                                                       \
     if (attr.first()) {                                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)fused_gemv_kernel<MT, OCT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+      (void)hipFuncSetAttribute((const void*)fused_gemv_kernel<MT, OCT, PRO, EPI, NPRE>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 (int)lds_);                                                                                              \
       attr.done();                                                                                                                       \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((fused_gemv_kernel<MT, OCT, PRO, EPI>), dim3(nblk, KS), dim3(256), lds_, st, g);                                      \
+    hipLaunchKernelGGL((fused_gemv_kernel<MT, OCT, PRO, EPI, NPRE>), dim3(nblk, KS), dim3(256), lds_, st, g);                               \
   } while (0)
+#define FG_GO(MT, OCT, PRO, EPI) FG_GO1(MT, OCT, PRO, EPI, (OCT == 8 && MT == 8 ? 16 : 8))  /* (16 rows x 16 in flight would spill) */
 #define FG_PE(MT, OCT)                                                      \
   do {                                                                       \
     if (pro == 1 && epi == 0) FG_GO(MT, OCT, 1, 0);                          \
@@ -1156,6 +1168,7 @@ int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t 
     else { if (w.oct == 8) FG_PE(16, 8); else FG_PE(16, 1); }
 #undef FG_PE
 #undef FG_GO
+#undef FG_GO1
     KK_CHECK_LAUNCH();
   }
   return 0;

@@ -993,13 +993,14 @@ struct Ctx {
       const bool v4 = w.wf && out.dtype == KK_BF16 && !cx->no_v4;
       g.wf = v4 ? w.wf : nullptr;
       // variant 5 (wave-specialised, persistent) takes the stride-1 convolutions; the polyphase transposed ones stay on variant 4
-      // measured per shape: 3-9 % faster than variant 4 on the 11-tap layers, level on 7 taps, 10-25 % slower on 3 taps
+      // measured per shape: 3-9 % faster than variant 4 on the 11-tap layers, level on 7 taps, 10-25 % slower on 3 taps; round 3 (16x16x32
+      // MFMA in both): also 2 % faster on the 7-tap layers of stage 0 (256 channels = 4 slabs per tile: more periods to spread the service work over)
       static int v5_min_taps = -1;
       if (v5_min_taps < 0) {
         const char* e = getenv("KK_V5_MIN_TAPS");  // (experiments)
         v5_min_taps = e ? atoi(e) : 9;
       }
-      const bool v5 = v4 && cx->v5_mode != 2 && (cx->v5_mode == 1 || g.Kw >= v5_min_taps) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
+      const bool v5 = v4 && cx->v5_mode != 2 && (cx->v5_mode == 1 || g.Kw >= v5_min_taps || (g.Kw >= v5_min_taps - 2 && g.CinP >= 256)) && B <= 256 && kk_mfma_tile_rows(Q) == 192 &&
                       kk_mfma5_eligible(g, out.dtype);
       // Linear layers over short utterances (Albert, T = 130 rows per item): the rows of a dense [B][T][C] tensor as ONE flat item, so that the
       // 192-row tiles run across utterance boundaries (32 x 130 rows = 22 tiles instead of 32).  k = 1, so rows do not interact; input rows past
