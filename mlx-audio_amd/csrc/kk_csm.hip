@@ -637,6 +637,7 @@ struct FGArgs {
   const float* res; long long rrs;  // EPI 1
   float* out; long long ors;
   long long pss;                    // EPI 2: floats between the partial tiles of consecutive K slices
+  int dbg;                          // KK_CSM_DBG (TIMING ONLY, wrong results): 1 no input staging, 2 no FMAs, 4 no reduction, 8 no weight loads
 };
 
 // h[m][n] += sum over the K slices of a split-K launch (slice order): the combine of the deep down projections
@@ -654,8 +655,15 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, 
   h[e] = h0 + t;
 }
 
+// sum over the 32 lanes of a half wave (butterfly)
+__device__ __forceinline__ float q32_sum(float v) {
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // 16-byte weight load that is not kept in the caches (a frame reads every matrix once; MI355X_MICROARCH.md nt-weights: -5 ... -10 % per layer)
-__device__ __forceinline__ uint4 ld_w_nt(const uint4* p) {
+__device__ __forceinline__ uint4 ld_w_nt(const uint4* p, int dbg = 0) {
+  if (dbg & 8) return make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -667,7 +675,7 @@ template <int MT, int OCT, int PRO, int EPI, int NPRE>
 __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
   constexpr int CB = 8 * OCT, KSUB = 64 / OCT, MP = MT / 2, NQ = MT / 4, OUT = CB * 8;
   constexpr int KCH = 16384 / MT;           // k rows staged at a time: xs is 64 KB (2048 rows for 8 input rows, 1024 for 16)
-  constexpr int NH = PRO == 2 ? 2 : 1;      // the gated prologue holds two values per item: two half passes
+  constexpr int NH = (PRO == 2 && KCH / 4 / 256 >= 2) ? 2 : 1;  // the gated prologue holds two values per item: two half passes where there is more than one quad per thread
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xs = sm;                                   // [NQ][KCH][4]
   float* red = sm;                                  // [4 waves][KSUB][OUT] (aliases xs after the main loop)
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int L = wave + 4 * i;
-      wpre[i] = ld_w_nt(wblk + (long long)(k_lo + (L < nL0 ? L : wave % nL0) * KSUB + ksub) * OCT);
+      wpre[i] = ld_w_nt(wblk + (long long)(k_lo + (L < nL0 ? L : wave % nL0) * KSUB + ksub) * OCT, a.dbg);
     }
   }
   // input row m of this launch as an element offset from its base (PRO 3: an item's last row comes from the audio embedding table,
@@ -734,6 +742,9 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
     __syncthreads();
     if (tid < MT) rs[tid] = 1.0f / sqrtf((((red2[tid] + red2[16 + tid]) + red2[32 + tid]) + red2[48 + tid]) / (float)K + a.eps);
   }
+  float ssq[MT];  // PRO 1 with the whole row in one chunk: sums of squares of this thread's share of every input row
+#pragma unroll
+  for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
   sk2f acc[8][MP];
 #pragma unroll
   for (int c = 0; c < 8; ++c)
@@ -742,59 +753,59 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
   for (int kc = k_lo; kc < k_hi; kc += KCH) {
     const int kn = min(KCH, k_hi - kc);
     __syncthreads();  // (the previous chunk's readers are done)
-    // ---- stage the chunk: thread t takes k = t, t + 256, ... and reads that column of EVERY input row (coalesced along k), one 16-byte LDS
-    // store per row quad.  All of a pass's loads are requested before anything is computed; with the norm prologue the row norms come out
-    // of the same registers (x is read once).
+    // ---- stage the chunk (round 3: 16-byte loads): thread t takes the k QUADS t, t + 256, ... of EVERY input row (one float4 per row, coalesced
+    // along k; round 2 read single floats, half of them clamped duplicates) and writes one 16-byte LDS store per (k, row quad).  With the norm
+    // prologue and the whole row in this chunk the row scale is NOT on the way in: x * w is staged, the sums of squares stay in registers through
+    // the main loop and rms^-1 multiplies the finished dot products (defer_rs): no reduction + two barriers ahead of the weight stream.
+    const bool defer_rs = PRO == 1 && K <= KCH;
+    if (!(a.dbg & 1))
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
-      constexpr int NIK = KCH / 256 / NH;  // k values per thread and pass
-      float g[NIK][MT], u[PRO == 2 ? NIK : 1][MT];
+      constexpr int NI4 = KCH / 4 / 256 / NH;  // k quads per thread and pass
+      float4 g[NI4][MT], u[PRO == 2 ? NI4 : 1][MT], nw4[PRO == 1 ? NI4 : 1];
+      const int nq = kn >> 2;
 #pragma unroll
-      for (int i = 0; i < NIK; ++i) {
-        const int k = tid + 256 * (hh * NIK + i);
-        const int kk = kc + (k < kn ? k : tid % kn);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          g[i][m] = rowptr(m)[kk];
-          if (PRO == 2) u[i][m] = rowptr(m)[K + kk];
-        }
-      }
-      if (PRO == 1 && K <= KCH) {  // the whole row is in this chunk: sums of squares from the registers
-        float ssq[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NIK; ++i)
-          if (tid + 256 * i < kn)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) ssq[m] = __builtin_fmaf(g[i][m], g[i][m], ssq[m]);
+      for (int i = 0; i < NI4; ++i) {
+        const int k4 = tid + 256 * (hh * NI4 + i);
+        const int kk = kc + 4 * (k4 < nq ? k4 : tid % nq);
+        if (PRO == 1) nw4[i] = *(const float4*)(a.nw + kk);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          float t = ssq[m];
-          for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-          if (lane == 0) red2[wave * 16 + m] = t;
+          g[i][m] = *(const float4*)(rowptr(m) + kk);
+          if (PRO == 2) u[i][m] = *(const float4*)(rowptr(m) + K + kk);
         }
-        __syncthreads();
-        if (tid < MT) rs[tid] = 1.0f / sqrtf((((red2[tid] + red2[16 + tid]) + red2[32 + tid]) + red2[48 + tid]) / (float)K + a.eps);
-        __syncthreads();
       }
 #pragma unroll
-      for (int i = 0; i < NIK; ++i) {
-        const int k = tid + 256 * (hh * NIK + i);
-        if (k < kn) {
-          const float nwk = PRO == 1 ? a.nw[kc + k] : 1.0f;
+      for (int i = 0; i < NI4; ++i) {
+        const int k4 = tid + 256 * (hh * NI4 + i);
+        if (k4 < nq) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            float4 t = g[i][m];
+            if (PRO == 2) {
+              const float4 uu = u[i][m];
+              t.x = t.x / (1.0f + expf(-t.x)) * uu.x; t.y = t.y / (1.0f + expf(-t.y)) * uu.y;
+              t.z = t.z / (1.0f + expf(-t.z)) * uu.z; t.w = t.w / (1.0f + expf(-t.w)) * uu.w;
+            } else if (PRO == 1) {
+              if (defer_rs) {
+                ssq[m] = __builtin_fmaf(t.x, t.x, ssq[m]); ssq[m] = __builtin_fmaf(t.y, t.y, ssq[m]);
+                ssq[m] = __builtin_fmaf(t.z, t.z, ssq[m]); ssq[m] = __builtin_fmaf(t.w, t.w, ssq[m]);
+                t.x *= nw4[i].x; t.y *= nw4[i].y; t.z *= nw4[i].z; t.w *= nw4[i].w;
+              } else {
+                const float r = rs[m];
+                t.x = t.x * r * nw4[i].x; t.y = t.y * r * nw4[i].y; t.z = t.z * r * nw4[i].z; t.w = t.w * r * nw4[i].w;
+              }
+            }
+            if (m >= M) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i][m] = t;
+          }
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int m = 4 * q + j;
-              float t = g[i][m];
-              if (PRO == 2) t = t / (1.0f + expf(-t)) * u[i][m];
-              else if (PRO == 1) t = t * rs[m] * nwk;
-              v[j] = m < M ? t : 0.f;
-            }
-            *(float4*)(xs + ((long long)q * KCH + k) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            float* d = xs + ((long long)q * KCH + 4 * k4) * 4;
+            *(float4*)(d) = make_float4(g[i][4 * q].x, g[i][4 * q + 1].x, g[i][4 * q + 2].x, g[i][4 * q + 3].x);
+            *(float4*)(d + 4) = make_float4(g[i][4 * q].y, g[i][4 * q + 1].y, g[i][4 * q + 2].y, g[i][4 * q + 3].y);
+            *(float4*)(d + 8) = make_float4(g[i][4 * q].z, g[i][4 * q + 1].z, g[i][4 * q + 2].z, g[i][4 * q + 3].z);
+            *(float4*)(d + 12) = make_float4(g[i][4 * q].w, g[i][4 * q + 1].w, g[i][4 * q + 2].w, g[i][4 * q + 3].w);
           }
         }
       }
@@ -802,6 +813,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
     __syncthreads();
     const int nL = kn / KSUB;  // wave loads in this chunk; wave w takes L = w, w + 4, ...
     auto fma_row = [&](const uint4& wq, int kl, float live) __attribute__((always_inline)) {
+      if (a.dbg & 2) { acc[0][0].x += __uint_as_float(wq.x ^ wq.y ^ wq.z ^ wq.w) * live; return; }
       sk2f xv[MP];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -827,7 +839,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
         const int L = wave + 4 * i;
-        wpre[i] = ld_w_nt(wblk + (long long)(kc + (L < nL ? L : wave % nL) * KSUB + ksub) * OCT);
+        wpre[i] = ld_w_nt(wblk + (long long)(kc + (L < nL ? L : wave % nL) * KSUB + ksub) * OCT, a.dbg);
       }
     }
     int L0 = wave;
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
       for (int i = 0; i < NPRE; ++i) {
         const int L = L0 + 4 * i, Ln = L + 4 * NPRE;
         const uint4 wq = wpre[i];
-        wpre[i] = ld_w_nt(wblk + (long long)(kc + (Ln < nL ? Ln : L) * KSUB + ksub) * OCT);
+        wpre[i] = ld_w_nt(wblk + (long long)(kc + (Ln < nL ? Ln : L) * KSUB + ksub) * OCT, a.dbg);
         fma_row(wq, L * KSUB + ksub, 1.0f);
       }
     }
@@ -844,6 +856,21 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
     for (int i = 0; i < NPRE; ++i) {  // the last ring-full: nothing left to request
       const int L = L0 + 4 * i;
       fma_row(wpre[i], (L < nL ? L : wave % nL) * KSUB + ksub, L < nL ? 1.0f : 0.0f);
+    }
+  }
+  if (a.dbg & 4) {  // (timing only)
+    if (acc[0][0].x == 123.456f) a.out[tid] = acc[1][1].y;
+    return;
+  }
+  // deferred RMSNorm scale: the waves' sums of squares -> LDS (visible behind the barriers below), applied to the finished dot products
+  const bool defer_rs_out = PRO == 1 && K <= KCH;
+  float* rsp = rs + 16;  // [4 waves][16]
+  if (defer_rs_out) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float t = ssq[m];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) rsp[wave * 16 + m] = t;
     }
   }
   // ---- reduction over the lanes that share columns (k-sub) and the 4 waves, 8 rows per pass; output o = mloc * CB + column
@@ -873,6 +900,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
       const int m = 8 * mh + mloc, n = nb * CB + col;
       if (m < M && n < a.N) {
         float t = ((red2[o] + red2[OUT + o]) + red2[2 * OUT + o]) + red2[3 * OUT + o];  // wave order
+        if (defer_rs_out) t *= 1.0f / sqrtf((((rsp[m] + rsp[16 + m]) + rsp[32 + m]) + rsp[48 + m]) / (float)K + a.eps);
         if (EPI == 1) t += a.res[(long long)m * a.rrs + n];
         if (EPI == 2) a.out[(long long)blockIdx.y * a.pss + (long long)m * a.ors + n] = t;  // K slice blockIdx.y of a split-K launch
         else a.out[(long long)m * a.ors + n] = t;
@@ -881,10 +909,160 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// gemv8_kernel (round 3): the same product for M <= 8 rows and a single K chunk (K per slice <= 2048, a multiple of 128) in COMPACT code.
+// What the phase ablation of fused_gemv_kernel showed (KK_CSM_DBG): with the input staging, the FMAs, the reduction AND the
+// weight loads all switched off a frame still took 6.1 of 9.6 ms -- ~6 us per launch of an empty kernel -- and the time followed the
+// amount of straight-line CODE on the executed path, not the work: the kernels are 16-38 KB of fully unrolled instructions that run
+// once per launch, i.e. a launch is bound by instruction fetch from a cold instruction cache.  This kernel keeps the arithmetic and its
+// order (a row's bits are those of fused_gemv_kernel up to where the RMSNorm scale is applied) and shrinks the code:
+//   * staging: thread (row = tid / 32, lane32) takes the k quads lane32, lane32 + 32, ... of ONE row (8 float4 in flight per pass) instead of
+//     one column of every row; sums of squares stay per row half-wave (5 shuffle steps once, not 6 per row); fast exp / reciprocal in SwiGLU;
+//   * weight stream: ring of 8 loads per wave, a ROLLED loop over rounds of 8 (use + refill), then one use-only round;
+//   * the RMSNorm scale multiplies the finished dot products (no reduction + barriers ahead of the weight stream).
+template <int OCT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemv8_kernel(FGArgs a) {
+  constexpr int CB = 8 * OCT, KSUB = 64 / OCT, OUT = CB * 8, KCH = 2048, RING = 8;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;                     // [8 rows][KCH] row-major: staged by conflict-free 16-byte stores, read as 8 broadcast words per k
+  float* red = sm;                    // [4 waves][KSUB][OUT] (aliases xs after the main loop)
+  float* red2 = sm + 4 * KSUB * OUT;  // [4][OUT]
+  float* rsq = red2 + 4 * OUT;        // [8] sums of squares of the input rows (PRO 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int oct = lane % OCT, ksub = lane / OCT;
+  const int nb = blockIdx.x, K = a.K, M = a.M;
+  const int Kper = K / gridDim.y, k_lo = blockIdx.y * Kper;
+  const int nL = Kper / KSUB;  // wave loads of this workgroup; wave w takes L = w, w + 4, ...
+  const uint4* wblk = (const uint4*)(a.w + (long long)nb * K * CB) + oct + (long long)k_lo * OCT;  // row k of the slice at + k * OCT uint4
+  // ---- the ring's first loads go out before anything else
+  uint4 ring[RING];
+#pragma unroll
+  for (int i = 0; i < RING; ++i) {
+    const int L = wave + 4 * i;
+    ring[i] = ld_w_nt(wblk + (long long)((L < nL ? L : wave % nL) * KSUB + ksub) * OCT, a.dbg);
+  }
+  // ---- stage the input rows
+  {
+    const int m = tid >> 5, l32 = tid & 31, mm = m < M ? m : 0;
+    const float* row;
+    if (PRO == 3) {  // an item's last row comes from the audio embedding table (sesame.py:373-392), its other rows from x
+      const int item = mm / a.rows, r = mm - item * a.rows;
+      row = r == a.rows - 1 ? a.emb + (long long)(a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
+    } else {
+      row = a.x + (long long)mm * a.xrs;
+    }
+    float ssq = 0.f;
+    float* dst = xs + (long long)m * KCH;
+    const int nq = Kper >> 2;  // k quads of the slice: a multiple of 32 (launcher)
+    for (int j0 = 0; j0 < nq; j0 += 32 * 8) {  // 8 quads per thread in flight (K = 1024: one pass)
+      float4 g[8], u[PRO == 2 ? 8 : 1], nw[PRO == 1 ? 8 : 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = j0 + l32 + 32 * j, qc = q < nq ? q : l32;
+        g[j] = *(const float4*)(row + k_lo + 4 * qc);
+        if (PRO == 2) u[j] = *(const float4*)(row + K + k_lo + 4 * qc);
+        if (PRO == 1) nw[j] = *(const float4*)(a.nw + k_lo + 4 * qc);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = j0 + l32 + 32 * j;
+        float4 t = g[j];
+        if (PRO == 2) {  // silu(gate) * up
+          t.x = t.x * __builtin_amdgcn_rcpf(1.0f + __expf(-t.x)) * u[j].x; t.y = t.y * __builtin_amdgcn_rcpf(1.0f + __expf(-t.y)) * u[j].y;
+          t.z = t.z * __builtin_amdgcn_rcpf(1.0f + __expf(-t.z)) * u[j].z; t.w = t.w * __builtin_amdgcn_rcpf(1.0f + __expf(-t.w)) * u[j].w;
+        } else if (PRO == 1) {
+          const float live = q < nq ? 1.0f : 0.0f;  // (a clamped duplicate of a ragged pass does not count)
+          ssq = __builtin_fmaf(t.x * live, t.x, ssq); ssq = __builtin_fmaf(t.y * live, t.y, ssq);
+          ssq = __builtin_fmaf(t.z * live, t.z, ssq); ssq = __builtin_fmaf(t.w * live, t.w, ssq);
+          t.x *= nw[j].x; t.y *= nw[j].y; t.z *= nw[j].z; t.w *= nw[j].w;
+        }
+        if (m >= M) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) *(float4*)(dst + 4 * q) = t;
+      }
+    }
+    if (PRO == 1) {
+      ssq = q32_sum(ssq);
+      if (l32 == 0) rsq[m] = ssq;  // (its own LDS words: visible behind the barriers below)
+    }
+  }
+  sk2f acc[8][4];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = sk2f{0.f, 0.f};
+  __syncthreads();
+  auto fma_row = [&](const uint4& wq, int kl, float live) __attribute__((always_inline)) {
+    const float* xp = xs + kl;
+    const sk2f xv[4] = {sk2f{xp[0], xp[KCH]}, sk2f{xp[2 * KCH], xp[3 * KCH]}, sk2f{xp[4 * KCH], xp[5 * KCH]}, sk2f{xp[6 * KCH], xp[7 * KCH]}};
+    const unsigned wd[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      const float w0 = __uint_as_float(wd[c2] << 16) * live, w1 = __uint_as_float(wd[c2] & 0xffff0000u) * live;
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        acc[2 * c2][mp] = __builtin_elementwise_fma(xv[mp], sk2f{w0, w0}, acc[2 * c2][mp]);
+        acc[2 * c2 + 1][mp] = __builtin_elementwise_fma(xv[mp], sk2f{w1, w1}, acc[2 * c2 + 1][mp]);
+      }
+    }
+  };
+  int L0 = wave;
+#pragma unroll 1
+  for (; L0 + 4 * RING < nL; L0 += 4 * RING) {  // every slot of this round has a successor (clamped in the last round of a ragged count)
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+      const int L = L0 + 4 * i, Ln = L + 4 * RING;
+      const uint4 wq = ring[i];
+      ring[i] = ld_w_nt(wblk + (long long)((Ln < nL ? Ln : L) * KSUB + ksub) * OCT, a.dbg);
+      fma_row(wq, L * KSUB + ksub, 1.0f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RING; ++i) {  // the last ring-full: nothing left to request
+    const int L = L0 + 4 * i;
+    fma_row(ring[i], (L < nL ? L : wave % nL) * KSUB + ksub, L < nL ? 1.0f : 0.0f);
+  }
+  // ---- reduction over the lanes that share columns (k-sub) and the 4 waves; output o = m * CB + column
+  __syncthreads();  // xs is no longer read
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* d = red + ((long long)(wave * KSUB + ksub)) * OUT + oct * 8 + c;
+      d[(2 * i) * CB] = acc[c][i].x;
+      d[(2 * i + 1) * CB] = acc[c][i].y;
+    }
+  __syncthreads();
+  for (int pr = tid; pr < 4 * OUT; pr += 256) {  // (wave q, output o): the q-th wave's KSUB lanes in k-sub order
+    const int q = pr / OUT, o = pr - q * OUT;
+    const float* sp = red + (long long)q * KSUB * OUT + o;
+    float t = 0.f;
+#pragma unroll 8
+    for (int ks = 0; ks < KSUB; ++ks) t += sp[(long long)ks * OUT];
+    red2[pr] = t;
+  }
+  __syncthreads();
+  for (int o = tid; o < OUT; o += 256) {
+    const int m = o / CB, col = o - m * CB, n = nb * CB + col;
+    if (m < M && n < a.N) {
+      float t = ((red2[o] + red2[OUT + o]) + red2[2 * OUT + o]) + red2[3 * OUT + o];  // wave order
+      if (PRO == 1) t *= 1.0f / sqrtf(rsq[m] / (float)K + a.eps);
+      if (EPI == 1) t += a.res[(long long)m * a.rrs + n];
+      if (EPI == 2) a.out[(long long)blockIdx.y * a.pss + (long long)m * a.ors + n] = t;  // K slice blockIdx.y of a split-K launch
+      else a.out[(long long)m * a.ors + n] = t;
+    }
+  }
+}
+template <int OCT>
+static size_t g8_lds_bytes() {
+  constexpr size_t xsb = (size_t)65536, redb = (size_t)4 * (64 / OCT) * (8 * OCT * 8) * 4;
+  return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64;
+}
+
 template <int MT, int OCT>
 static size_t fg_lds_bytes() {
   constexpr size_t xsb = (size_t)65536, redb = (size_t)4 * (64 / OCT) * (8 * OCT * 8) * 4;
-  return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64;
+  return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64 + 256;  // + rs [16] + the waves' sums of squares [4][16]
 }
 
 // ------------------------------------------------------------------------------------------------------------- host
@@ -1127,6 +1305,11 @@ int gemv_slices(const Lin& w) {
 int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st, int KS = 1) {
   if (!w.wb || !w.oct) return kk_fail("kk_csm: internal: fused GEMV without a block pack");
   a.w = w.wb; a.K = w.Cin; a.N = w.Cout;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("KK_CSM_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
+  }
   const int CB = 8 * w.oct, nblk = (w.Cout + CB - 1) / CB;
   if ((epi == 2) != (KS > 1 || epi == 2)) return kk_fail("kk_csm: internal: split-K form");
   for (int m0 = 0; m0 < Mtot; m0 += 16) {
@@ -1163,6 +1346,40 @@ int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t 
     else if (pro == 0 && epi == 0) FG_GO(MT, OCT, 0, 0);                     \
     else return kk_fail("kk_csm: internal: fused GEMV form");                \
   } while (0)
+    // M <= 8 rows and one K chunk: the compact kernel (gemv8_kernel); KK_CSM_OLD=1 keeps the round-2 kernel for A/B timing
+    static int old_kernel = -1, g8_mask = 0xFF;
+    if (old_kernel < 0) {
+      old_kernel = getenv("KK_CSM_OLD") ? 1 : 0;
+      if (getenv("KK_CSM_G8_MASK")) g8_mask = atoi(getenv("KK_CSM_G8_MASK"));  // (debugging: bit p = prologue p on the compact kernel; bit 4 + oct/8)
+    }
+    const int kper = a.K / KS;
+    if (!old_kernel && ((g8_mask >> pro) & 1) && ((g8_mask >> (4 + (w.oct == 8 ? 1 : 0))) & 1) && g.M <= 8 && kper <= 2048 && kper % 128 == 0) {
+#define G8_GO(OCT, PRO, EPI)                                                                                                             \
+  do {                                                                                                                                   \
+    static KKDevOnce attr;                                                                                                               \
+    const size_t lds_ = (g8_lds_bytes<OCT>());                                                                                           \
+    if (attr.first()) {                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)gemv8_kernel<OCT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);        \
+      attr.done();                                                                                                                       \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL((gemv8_kernel<OCT, PRO, EPI>), dim3(nblk, KS), dim3(256), lds_, st, g);                                           \
+  } while (0)
+#define G8_PE(OCT)                                                          \
+  do {                                                                       \
+    if (pro == 1 && epi == 0) G8_GO(OCT, 1, 0);                              \
+    else if (pro == 0 && epi == 1) G8_GO(OCT, 0, 1);                         \
+    else if (pro == 2 && epi == 1) G8_GO(OCT, 2, 1);                         \
+    else if (pro == 2 && epi == 2) G8_GO(OCT, 2, 2);                         \
+    else if (pro == 3 && epi == 0) G8_GO(OCT, 3, 0);                         \
+    else if (pro == 0 && epi == 0) G8_GO(OCT, 0, 0);                         \
+    else return kk_fail("kk_csm: internal: fused GEMV form");                \
+  } while (0)
+      if (w.oct == 8) G8_PE(8); else G8_PE(1);
+#undef G8_PE
+#undef G8_GO
+      KK_CHECK_LAUNCH();
+      continue;
+    }
     // MT depends on the rows per launch only through "fits in 8": a row's arithmetic is the same in both instantiations
     if (g.M <= 8) { if (w.oct == 8) FG_PE(8, 8); else FG_PE(8, 1); }
     else { if (w.oct == 8) FG_PE(16, 8); else FG_PE(16, 1); }

@@ -503,3 +503,71 @@ def test_csm_shared_weights_two_generators_in_flight():
     np.testing.assert_array_equal(got[1], want[1])
     del b  # the shared generator goes first; the weights stay with `a`
     np.testing.assert_array_equal(run(a, *prompts[1]), want[1])
+
+
+def test_csm_full_depth_config4_batch8():
+    """BASELINE config 4 at FULL size: P.csm_config() unmodified -- 16 + 4 layers, 2 051-entry audio vocabulary, 32 code
+    books, 2 048-slot caches -- B = 8 streams with RAGGED prompts of up to 190 positions (left-padded, kk_csm_set_padding), bf16 weight
+    storage as `bench.py --config csm` runs it, then 4 single-token frames:
+      * graph replay == eager: every code and every logit bit-identical;
+      * stream b alone (B = 1) == stream b in the batch, bit-identical;
+      * frame-0 logits of ONE stream against the CPU oracle (fp32 arithmetic on the same bf16-rounded weights) within 2e-4, its codes equal."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_config()
+    w = _as_bf16_checkpoint(P.csm_synth_checkpoint(cfg, 0))
+    rng = np.random.default_rng(44)
+    B, n, V = 8, cfg["audio_num_codebooks"], cfg["audio_vocab_size"]
+    lens = [190, 131, 190, 64, 177, 190, 99, 150]
+    S = max(lens)
+    tok = np.zeros((B, S, n + 1), np.int64)
+    msk = np.zeros((B, S, n + 1), np.float32)
+    for b, L in enumerate(lens):  # [text | audio frames], right-aligned: the first S - L positions are padding (all-zero mask)
+        nt = L // 3
+        tok[b, S - L : S - L + nt, -1] = rng.integers(0, cfg["text_vocab_size"], nt)
+        msk[b, S - L : S - L + nt, -1] = 1
+        tok[b, S - L + nt :, :n] = rng.integers(0, V, (L - nt, n))
+        msk[b, S - L + nt :, :n] = 1
+    us = rng.uniform(size=(4, B, n)).astype(np.float32)
+
+    def run(model, sel, graph):
+        model.reset_caches()
+        model.set_graph_mode(graph)
+        pads = [S - lens[b] for b in sel]
+        lo = min(pads)  # a lone stream needs no common padding: drop what every selected stream shares
+        model.set_padding([p - lo for p in pads])
+        codes = [model.generate_frame(torch.tensor(tok[sel][:, lo:]), torch.tensor(msk[sel][:, lo:])).clone()]
+        logits = [model.debug_logits().clone()]
+        for i in range(4):
+            t_in = torch.zeros((len(sel), 1, n + 1), dtype=torch.int32, device="cuda")
+            t_in[:, 0, :n] = codes[-1]
+            m_in = torch.zeros((len(sel), 1, n + 1), dtype=torch.float32, device="cuda")
+            m_in[:, 0, :n] = 1
+            temp, u = (0.9, torch.tensor(us[i][sel])) if i % 2 else (0.0, None)
+            codes.append(model.generate_frame(t_in, m_in, temperature=temp, top_k=50, uniforms=u).clone())
+            logits.append(model.debug_logits().clone())
+        torch.cuda.synchronize()
+        return torch.stack(codes).cpu().numpy(), torch.stack(logits).cpu().numpy()  # [5][B][n], [5][n][B][V]
+
+    model = SesameModel(cfg, w, weight_dtype="bfloat16")
+    model.setup_caches(B)
+    allb = list(range(B))
+    c_e, l_e = run(model, allb, False)
+    for _ in range(3):  # eager, capture, replay of the single-token frame graph
+        c_g, l_g = run(model, allb, True)
+    np.testing.assert_array_equal(c_g, c_e)
+    np.testing.assert_array_equal(l_g, l_e)
+    for b in (3, 0):  # the shortest and a full-length stream, alone
+        c_1, l_1 = run(model, [b], False)
+        np.testing.assert_array_equal(c_1[:, 0], c_e[:, b])
+        np.testing.assert_array_equal(l_1[:, :, 0], l_e[:, :, b])
+    # the oracle on stream 3 (64 positions: the CPU cost is per position), frame 0
+    b = 3
+    orc = C.CsmOracle(w, cfg)
+    trace = {}
+    ref = orc.generate_frame(tok[b : b + 1, S - lens[b]:], msk[b : b + 1, S - lens[b]:], trace=trace)
+    ref_lg = np.stack([trace["c0_logits"]] + trace["ci_logits"], 0)[:, 0]  # [n][V]
+    e = err_stats(l_e[0][:, b], ref_lg)
+    report("csm/full_depth/frame0/logits_stream3", **e)
+    assert e["rel_max"] < 2e-4, e
+    np.testing.assert_array_equal(c_e[0][b], ref[0])
