@@ -510,7 +510,10 @@ def test_csm_full_depth_config4_batch8():
     books, 2 048-slot caches -- B = 8 streams with RAGGED prompts of up to 190 positions (left-padded, kk_csm_set_padding), bf16 weight
     storage as `bench.py --config csm` runs it, then 4 single-token frames:
       * graph replay == eager: every code and every logit bit-identical;
-      * stream b alone (B = 1) == stream b in the batch, bit-identical;
+      * stream b alone (B = 1, its own unpadded prompt) vs stream b in the batch: every sampled code equal, logits within 2e-5 of their range --
+        NOT bit-identical at this size (measured 5e-6): the prompt block's skinny GEMMs split K by the number of rows in flight (B x S), so the
+        summation order of the prompt's K / V entries depends on the batch; the single-token steps themselves are row-independent (the tiny-size
+        test_csm_streams_are_independent_bitexact holds bit for bit because its prompt takes one K slice either way);
       * frame-0 logits of ONE stream against the CPU oracle (fp32 arithmetic on the same bf16-rounded weights) within 2e-4, its codes equal."""
     from mlx_audio_amd.csm import SesameModel
 
@@ -560,7 +563,9 @@ def test_csm_full_depth_config4_batch8():
     for b in (3, 0):  # the shortest and a full-length stream, alone
         c_1, l_1 = run(model, [b], False)
         np.testing.assert_array_equal(c_1[:, 0], c_e[:, b])
-        np.testing.assert_array_equal(l_1[:, :, 0], l_e[:, :, b])
+        e1 = err_stats(l_1[:, :, 0], l_e[:, :, b])
+        report(f"csm/full_depth/alone_vs_batch/stream{b}", **e1)
+        assert e1["rel_max"] < 2e-5, e1
     # the oracle on stream 3 (64 positions: the CPU cost is per position), frame 0
     b = 3
     orc = C.CsmOracle(w, cfg)
