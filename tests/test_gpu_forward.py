@@ -580,6 +580,11 @@ def test_config2_slice_matches_oracle():
         # (measured on the other utterance: 0.01 % of the samples up to 0.08, rms 6e-3; the pass conditioned on the ORACLE's curves happens
         # not to hit one).  The rms bound keeps that to isolated flips.
         assert ef["p99_abs"] <= 1e-3 * max(1.0, ef["ref_max"]) and ef["rms_rel"] <= 2e-2, ef
+        # (p99 alone tolerates 1 % of the samples arbitrarily off.)  The samples outside the bar are the isolated +-pi flips:
+        # their FRACTION is bounded too (measured 0 and 0.04 %), and away from them the error is at round-off level (p99 1e-4)
+        bad = float((np.abs(r["wav_free"][b] - r["free_ref"][b]) > 1e-3 * max(1.0, ef["ref_max"])).mean())
+        report(f"config2/float32/free_running_vs_oracle_on_engine_f0/outside_bar/b{b}", fraction=bad)
+        assert bad <= 2e-3 and ef["p99_abs"] <= 2e-4 * max(1.0, ef["ref_max"]), (bad, ef)
         # ... and (ii) against the oracle's own free-running waveform by the phase-robust distances (measured on MI355X: lsd 3.9 / 5.0 dB,
         # band 2.0 / 2.6 dB; an unrelated utterance of the same checkpoint: 7.4 / 4.3 dB)
         d = _phase_robust(f"config2/float32/free_running/b{b}", r["wav_free"][b], a, r["o_audio"][1 - b])
@@ -597,14 +602,16 @@ def test_config2_slice_matches_oracle():
 
 
 # bf16 engine vs fp32 oracle at config-2 shapes: RMS-relative bounds per stage (measured values in the comment of each entry)
-# measured on MI355X (round 2, gpurun_out/parity_report.jsonl): gen_pre_res0 0.0063, gen_stage0 0.0073, gen_pre_res1 0.0071, gen_stage1 0.0083,
-# conv_post 0.0087; waveform 0.0136 rms, lsd 0.18 dB, band 0.08 dB.  Bounds = about 2.5x the measurement (bf16 keeps 8 significant bits).
-BF16_STAGE_RMS = {"gen_pre_res0": 0.015, "gen_stage0": 0.018, "gen_pre_res1": 0.018, "gen_stage1": 0.02, "conv_post": 0.022}
-BF16_WAV_RMS, BF16_WAV_LSD_DB, BF16_WAV_BAND_DB = 0.035, 0.5, 0.25
+# measured on MI355X (round 3, 16x16x32 MFMA convs, statistics from the fp32 values; gpurun_out/r3o/parity_forward.jsonl): gen_pre_res0 0.00627,
+# gen_stage0 0.0073, gen_pre_res1 0.00707, gen_stage1 0.0083, conv_post 0.00865; waveform 0.0129-0.0143 rms, lsd 0.18-0.20 dB, band 0.08-0.094 dB;
+# 0 duration mismatches.  Bounds = 1.5x the measurement (2.5x could hide a 2x accuracy regression of a conv variant).
+BF16_STAGE_RMS = {"gen_pre_res0": 0.0094, "gen_stage0": 0.011, "gen_pre_res1": 0.0106, "gen_stage1": 0.0125, "conv_post": 0.013}
+BF16_WAV_RMS, BF16_WAV_LSD_DB, BF16_WAV_BAND_DB = 0.0215, 0.30, 0.14
 
 
 def test_config2_bf16_benchmarked_path_matches_oracle():
-    """The BENCHMARKED path -- bf16 engine: variant-4 MFMA convs with the AdaIN + Snake fusion, conv_post, the fast iSTFT head -- at
+    """The BENCHMARKED path -- bf16 engine: the 16x16x32 MFMA convs (variant 4; variant 5 on the 11-tap layers and the 7-tap 256-channel ones) with
+    the AdaIN + Snake fusion and the statistics in their epilogues, the fused conv_post + iSTFT head -- at
     BASELINE config-2 shapes (T = 130, F = 650, B = 2, injected noise), against the fp32 oracle (kokoro.py:120-170, istftnet.py:769-807):
     text stage, decoder, then on the oracle's F0 / N curves the generator stages, conv_post and the waveform (RMS-relative and the
     phase-robust spectral distances); the free-running forward is held to the phase-robust distances."""
@@ -617,7 +624,7 @@ def test_config2_bf16_benchmarked_path_matches_oracle():
         mism = r["pred"][b, :T] != r["orc"].text_stage(utts[b], r["ref_s"][b : b + 1], 1.0)
         frac = np.abs(r["dur_f"][b, :T] - np.floor(r["dur_f"][b, :T]) - 0.5)
         report(f"config2_bf16/duration/b{b}", mismatches=int(mism.sum()), tokens=int(T), worst_margin=float(frac[mism].max()) if mism.any() else 0.0)
-        assert mism.sum() <= 2 and np.all(frac[mism] < 0.05), (mism.sum(), frac[mism])
+        assert mism.sum() <= 1 and np.all(frac[mism] < 0.02), (mism.sum(), frac[mism])
     for k, bound in BF16_STAGE_RMS.items():
         assert r["cond_rms"][k] < bound, (k, r["cond_rms"][k], bound)
     for b, a in enumerate(r["o_audio"]):
