@@ -524,7 +524,7 @@ def bench_kokoro(args, rank, world, quantization_kernel=None, brief=False):
         try:
             # PMC byte counts were taken at one batch size per configuration: B = 32 for the bf16 / fp32 entries, B = 64 for config 5
             key, pmc_batch = ("bfloat16+fp8 (config 5, B=64, r01_i)", 64) if (args.quantized and quantization_kernel == "mxfp8") else (args.dtype, 32)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(key) if B == pmc_batch else None
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))).get(key) if B == pmc_batch else None
         except Exception:
             pmc = None
         if prof is not None:

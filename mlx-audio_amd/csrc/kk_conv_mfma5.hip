@@ -544,6 +544,14 @@ __global__ __launch_bounds__(512, 2) void conv_mfma5_kernel(KKMfmaArgs a, int B)
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] += v2f{__uint_as_float(w4[k] << 16), __uint_as_float(w4[k] & 0xFFFF0000u)};
       }
+      if (a.post_slope != 0.f && a.post_slope != 1.0f) {  // (uniform) LeakyReLU of the finished value
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float mx = v[k].x * a.post_slope, my = v[k].y * a.post_slope;
+          v[k].x = v[k].x > mx ? v[k].x : mx;
+          v[k].y = v[k].y > my ? v[k].y : my;
+        }
+      }
       // rows past the utterance are stored as exact zeros (and count as zeros in the statistics); only a tile that reaches past its
       // utterance pays the selects (tile_full is uniform)
       if (!tile_full && !(lv && wr_ok)) {

@@ -168,6 +168,14 @@
             for (int k = 0; k < 4; ++k) v[k] += v2f{t.f[2 * k], t.f[2 * k + 1]};
           }
         }
+        if (a.post_slope != 0.f && a.post_slope != 1.0f) {  // (uniform) LeakyReLU of the finished value: max(v, slope v) for 0 < slope < 1
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float mx = v[k].x * a.post_slope, my = v[k].y * a.post_slope;
+            v[k].x = v[k].x > mx ? v[k].x : mx;
+            v[k].y = v[k].y > my ? v[k].y : my;
+          }
+        }
         if (sizeof(TO) == 2) {
           // rows past the utterance are stored as exact zeros; only a tile that reaches past it pays the selects (tile_full is uniform)
           if (!tile_full && !live[i]) {

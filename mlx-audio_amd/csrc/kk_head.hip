@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, (HD_ROWS == 256 ? 2 : 3)) void conv_post_istft
       if (r < HD_XROWS) {
         const unsigned msk = (row >= 0 && row < Tf) ? 0xFFFFFFFFu : 0u;
         unsigned w4[4] = {xr[i].x & msk, xr[i].y & msk, xr[i].z & msk, xr[i].w & msk};
+        if (slope != 1.0f)  // (uniform; 1 = the producer's epilogue applied the LeakyReLU already: the slab is a masked copy)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           // LeakyReLU with 0 < slope < 1 is max(x, slope * x): one packed multiply + one packed max per PAIR (the staging transform is

@@ -46,6 +46,7 @@ struct KKMfmaArgs {
   // stored as zeros past that item's length flat_len.  0 = off.
   int flat_T;
   KKLen flat_len;
+  float post_slope;  // variants 4 / 5 (bf16 out): LeakyReLU(post_slope) of the final stored value; 0 or 1 = none
 };
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase

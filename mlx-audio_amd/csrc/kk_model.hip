@@ -849,6 +849,7 @@ struct ConvOpt {
   bool want_stats = false;
   bool pad_out_ok = false;  // the destination may receive up to 7 extra zero channels (Cout rounded up to 8)
   double alg_taps_cin = 0;  // algorithmic taps*Cin of the op this launch implements, when the packed form carries structural zeros
+  float post_slope = 1.f;   // MFMA variants 4 / 5: LeakyReLU(post_slope) of the FINAL stored value (after residual, scale, accumulate); 1 = none
 };
 
 struct Ctx {
@@ -982,7 +983,7 @@ struct Ctx {
       if (o.res) { g.res = o.res->p; g.rbs = o.res->bs; g.ldr = o.res->ld; }
       g.Cout = w.Cout8; g.Kw = w.Kw; g.mode = o.mode; g.stride = o.stride; g.pad = o.pad; g.dil = o.dil; g.in_shift = o.in_shift;
       g.Q = Q; g.Lo_rows = out.rows; g.lin = lin; g.lout = lout; g.in_slope = o.in_slope; g.scale = o.scale; g.accumulate = o.accumulate;
-      g.act = o.act; g.act_slope = o.act_slope;
+      g.act = o.act; g.act_slope = o.act_slope; g.post_slope = o.post_slope;
       if (o.want_stats) {
         last_ntiles = kk_cdiv(Q, kk_mfma_stat_tile_rows(g, out.dtype)) * (o.mode == KK_CONVT ? o.stride : 1);
         if ((size_t)B * last_ntiles * 2 * w.Cout > fz_part_floats) return kk_fail("internal: statistics scratch too small");
@@ -1226,7 +1227,7 @@ int run_resblk1d(Ctx& c, const ResBlk1d& r, const Buf& x, KKLen lin, int Lmax_in
 // AdaINResBlock1 (istftnet.py:377-396).  Iteration 0 reads x_in; iterations keep their running value in y.
 // If acc != null the last iteration writes acc (+)= (conv + y) * acc_scale instead of y.
 int run_resblock1(Ctx& c, const ResBlock1& r, const Buf& x_in, const Buf& y, Buf& t1, Buf& t2, int Lmax, KKLen len, const float* style,
-                  int gbs, const Buf* acc, float acc_scale, int acc_accumulate, bool x_stats_ready = false) {
+                  int gbs, const Buf* acc, float acc_scale, int acc_accumulate, bool x_stats_ready = false, float post_slope = 1.f) {
   {
     ConvOpt p1, p2;
     p1.dil = r.dil[2]; p1.pad = (r.k * r.dil[2] - r.dil[2]) / 2;
@@ -1253,6 +1254,7 @@ int run_resblock1(Ctx& c, const ResBlock1& r, const Buf& x_in, const Buf& y, Buf
         if (j == 2 && acc) {
           o2.scale = acc_scale;
           o2.accumulate = acc_accumulate;
+          o2.post_slope = post_slope;
           KK_TRY(c.conv(r.c2[j], t2, len, *acc, len, Lmax, o2));
         } else {
           o2.want_stats = j < 2;
@@ -1530,6 +1532,11 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   KK_TRY(c.join_side(1));
   KK_TRY(c.dbg("har", har, 22));
   // ---- up-sampling stages (istftnet.py:776-796)
+  // The fused head will run (bf16 mode) and nobody looks at gen_stage1 / overrides a stage: the LeakyReLU(0.01) that conv_post applies to its
+  // input (istftnet.py:797) moves into the epilogue of the conv that finishes the generator's last stage, and the head's slab staging --
+  // a quarter of its vector instructions (profiles/r03_head_pmc.json) -- becomes a copy.
+  const bool post_lrelu = m->head_wf && !cx->no_head_fusion && !cx->force_generic && !cx->no_fusion && c.adt == KK_BF16 && !cx->keep_debug && cx->dbg_over.empty() &&
+                          !getenv("KK_NO_POST_LRELU");
   Buf cur = gx;           // input of ups[i]
   KKLen lcur = l2;
   int Lcur = L2;
@@ -1594,13 +1601,15 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     }
     KK_TRY(c.dbg(i == 0 ? "gen_pre_res0" : "gen_pre_res1", xi, Cst));
     for (int j = 0; j < nk; ++j)
-      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0, j > 0 || xi_stats));
+      KK_TRY(run_resblock1(c, m->resblocks[i * nk + j], xi, yb, t1, t2, Lst, lst, style_d, m->Nd, &accb, 1.0f / (float)nk, j > 0 ? 1 : 0, j > 0 || xi_stats,
+                           (last && j == nk - 1 && post_lrelu) ? 0.01f : 1.f));
     KK_TRY(c.dbg(i == 0 ? "gen_stage0" : "gen_stage1", accb, Cst));
     cur = accb;
     lcur = lst;
     Lcur = Lst;
   }
   // ---- conv_post + iSTFT head (istftnet.py:798-806)
+  // (post_lrelu: the LeakyReLU(0.01) in front of conv_post was applied by the epilogue of the last resblock conv -- the head then stages raw rows)
   Buf cp = c.act(Tf, 24);
   if (m->head_wf && !cx->no_head_fusion && !cx->force_generic && cur.dtype == KK_BF16 && cur.ld % 8 == 0 && cur.ld >= m->conv_post.Cin &&
       !((uintptr_t)cur.p & 15) && cx->dbg_over.find("conv_post") == cx->dbg_over.end()) {
@@ -1608,7 +1617,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
     if (!c.dry) {
       KKHeadArgs h;
       memset(&h, 0, sizeof h);
-      h.x = (const bf16_t*)cur.p; h.xbs = cur.bs; h.ldx = cur.ld; h.wf = m->head_wf; h.bias = m->conv_post.b; h.in_slope = 0.01f;
+      h.x = (const bf16_t*)cur.p; h.xbs = cur.bs; h.ldx = cur.ld; h.wf = m->head_wf; h.bias = m->conv_post.b; h.in_slope = post_lrelu ? 1.0f : 0.01f;
       h.len_frames = lens4 + 2 * B; h.Tfmax = Tf; h.wav = wav_out; h.wbs = (long long)Nw;
       if (cx->keep_debug) { h.cp_out = (bf16_t*)cp.p; h.cp_bs = cp.bs; h.cp_ld = cp.ld; }
       for (int n = 0; n < 20; ++n) h.hann_per[n] = (float)(0.5 * (1.0 - cos(2.0 * 3.14159265358979323846 * n / 20.0)));
@@ -1623,7 +1632,7 @@ int run_audio(Ctx& c, int Tmax, const int* lens, const float* ref_s, const int* 
   }
   ConvOpt op;
   op.pad = 3;
-  op.in_slope = 0.01f;
+  op.in_slope = post_lrelu ? 1.0f : 0.01f;
   op.pad_out_ok = true;  // cp has pitch 24 for 22 channels
   KK_TRY(c.conv(m->conv_post, cur, lTf, cp, lTf, Tf, op));
   KK_TRY(c.dbg("conv_post", cp, 22));

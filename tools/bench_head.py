@@ -24,7 +24,7 @@ wav = torch.empty(B, 5 * (Tf - 1), device="cuda")
 
 
 def call():
-    assert lib.kk_op_conv_post_istft(st(), B, P(x), Cn, Tf, None, P(wf), P(bias), C.c_float(0.01), P(wav), None, 0) == 0, lib.kk_last_error()
+    assert lib.kk_op_conv_post_istft(st(), B, P(x), Cn, Tf, None, P(wf), P(bias), C.c_float(float(os.environ.get("KK_HEAD_SLOPE", "0.01"))), P(wav), None, 0) == 0, lib.kk_last_error()
 
 
 for _ in range(3):
