@@ -21,6 +21,9 @@
 
 namespace {
 
+typedef float kk_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 kk_bf16x8 __attribute__((ext_vector_type(8)));
+
 struct Lin {  // generic-kernel pack [1][Cin][ldw]
   size_t off = 0;
   int Cin = 0, Cout = 0, ldw = 0;
@@ -30,6 +33,12 @@ struct Lin {  // generic-kernel pack [1][Cin][ldw]
   size_t boff = 0;
   const uint16_t* wb = nullptr;
   int oct = 0;  // 0 = no block pack (K not a multiple of 64)
+  // the same bf16 matrix in FRAGMENT order for the matrix-core GEMV (gemvm_kernel): [Cout / (16 nsub)][Cin / 32][nsub][64 lanes][8]: a wave
+  // load of 1 KiB is one 32 x 16 B operand of v_mfma_f32_16x16x32_bf16 (lane L: k = 32 c + 8 (L / 16) + j, n = 16 s + L % 16)
+  size_t moff = 0;
+  const uint16_t* wm = nullptr;
+  int nsub = 0;  // 0 = no fragment pack (K not a multiple of 32)
+  int ks = 1;    // split-K slices of a deep projection (K >= 4096): partial tiles + combine
 };
 struct Vec {
   size_t off = 0;
@@ -1065,6 +1074,182 @@ static size_t fg_lds_bytes() {
   return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64 + 256;  // + rs [16] + the waves' sums of squares [4][16]
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// gemvm_kernel (round 3): the single-token product on the MATRIX CORES, with every weight byte of the workgroup requested up front.
+// What the per-kernel times of gemv8_kernel showed (profiles/r03_b_csm_bf16w_kernel_stats.csv): 15.5 us for gate|up (33.5 MB: 2.2 TB/s),
+// 8.7 us for q|k|v (3 MB), 7.3 us for o (2 MB), while a chain of EMPTY kernels costs 1.55 us per launch in graph replay
+// (tools/gridbar/launchfloor.hip): a frame is bound by the latency INSIDE its kernels.  gemv8 keeps 8 loads x 4 waves = 32 KB in flight
+// per CU, so gate|up's 128 KB per workgroup are four exposed HBM round trips, and its 64 fp32 accumulators per lane (8 columns x 8 rows)
+// leave no registers for a deeper ring and need a 3-stage LDS reduction.  Here:
+//   * x (fp32, after the prologue) is split EXACTLY into three bf16 terms by truncation, x = x1 + x2 + x3 (8 + 8 + 8 significand bits:
+//     x1 = top half of x, x2 = top half of x - x1, x3 = x - x1 - x2, all subtractions exact), and the bf16 weights meet them in
+//     v_mfma_f32_16x16x32_bf16: products of two bf16 are exact in fp32 and the instruction accumulates in fp32, so the result is an
+//     fp32-arithmetic dot product of the fp32 input with the bf16 matrix -- what the round-2 kernels computed with v_pk_fma_f32 -- in a
+//     different summation order.  A (16 m x 32 k) carries the terms: m slot 4 (r / 2) + 2 t + r % 2 = term t of input row r, first
+//     instruction [x1 | x2], second [x3 | 0]; B (32 k x 16 n) is one 1-KiB wave load of the fragment pack.  A lane of the 16 x 16 result
+//     holds rows 2 g, 2 g + 1 (g = lane / 16) of column lane % 16 as acc[0] + acc[2], acc[1] + acc[3]: 4 accumulator registers per 16
+//     columns instead of 64, no cross-lane reduction at all, one 4-KiB-per-16-columns exchange between the 8 waves at the end.
+//     A row's result does not depend on the other rows of the launch (an output element of the instruction reads its own A row only).
+//   * 512 threads; wave w owns the 32-row K chunks w, w + 8, ... and all NSUB 16-column sub-blocks of them: 4 chunks x NSUB loads of
+//     16 bytes per lane go out BEFORE the input is staged (K = 1024, 64 columns: the whole 128 KB of the workgroup at once), later
+//     rounds (K = 2048) refill a slot as it is consumed.
+//   * staging: thread (row r = tid % 8, octet tid / 8 + 64 p) loads 8 consecutive k of its row, applies the prologue, splits, and writes
+//     four 16-byte A operands; the k-octet pitch inside a fragment is 288 bytes, so the 8 rows x 2 octets of a 16-lane group cover all
+//     64 banks once (the rows' m slots leave 32-byte holes that the next octet fills), and the MFMA-side read of 16 lanes is 256
+//     contiguous bytes.  LDS: 2304 bytes per 32 k (72 KB for K = 1024, 144 KB for K = 2048).
+//   * RMSNorm: sum of squares per row while staging (fixed order: lane butterfly, then waves 0..7), scale applied to the finished dot
+//     products; EPI as before.  grid = (column blocks, K slices, 8-row chunks of M).
+template <int NSUB, int PRO, int EPI>
+__global__ __launch_bounds__(512) void gemvm_kernel(FGArgs a) {
+  constexpr int KOP = 288, FRAG = 4 * KOP, CHB = 2 * FRAG;
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.x, K = a.K;
+  const int Kper = K / gridDim.y, k_lo = blockIdx.y * Kper;
+  const int nch = Kper >> 5;
+  const int m0 = blockIdx.z * 8;
+  const int M = a.M - m0 < 8 ? a.M - m0 : 8;
+  const int mainb = nch * CHB > NSUB * 4096 ? nch * CHB : NSUB * 4096;
+  char* xf = smc;                           // [nch][2 fragments][4 k octets at pitch 288][16 m slots][8 bf16]
+  float* red = (float*)smc;                 // [8 waves][NSUB][2][64] (aliases xf after the main loop)
+  float* rsq = (float*)(smc + mainb);       // [8 waves][8 rows] sums of squares (PRO 1)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* wblk = (const u32x4*)a.w + ((long long)nb * (K >> 5) + (k_lo >> 5)) * (NSUB * 64) + lane;  // chunk c, sub-block s at + (c NSUB + s) 64
+  // ---- the first round of weight loads goes out before anything else
+  u32x4 ring[4][NSUB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = wave + 8 * j;
+    if (c < nch) {
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)(c * NSUB + s) * 64);
+    }
+  }
+  // ---- stage the input rows: prologue, exact three-way bf16 split, fragment order
+  {
+    const int r = tid & 7, oi = tid >> 3, mg = m0 + (r < M ? r : 0);
+    const float* row;
+    if (PRO == 3) {  // an item's last row comes from the audio embedding table (sesame.py:373-392), its other rows from x
+      const int item = mg / a.rows, rr = mg - item * a.rows;
+      row = rr == a.rows - 1 ? a.emb + (long long)(a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
+    } else {
+      row = a.x + (long long)mg * a.xrs;
+    }
+    row += k_lo;
+    const float live = r < M ? 1.0f : 0.0f;
+    const int noct = Kper >> 3;
+    float ssq = 0.f;
+    char* dst0 = xf + (4 * (r >> 1) + (r & 1)) * 16;
+    for (int o0 = 0; o0 < noct; o0 += 128) {  // two octets per thread in flight (K = 1024: one pass)
+      float4 g[2][2], u[PRO == 2 ? 2 : 1][2], nw[PRO == 1 ? 2 : 1][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int o = o0 + oi + 64 * p, oc = o < noct ? o : 0;
+        g[p][0] = *(const float4*)(row + 8 * oc); g[p][1] = *(const float4*)(row + 8 * oc + 4);
+        if (PRO == 2) { u[p][0] = *(const float4*)(row + K + 8 * oc); u[p][1] = *(const float4*)(row + K + 8 * oc + 4); }
+        if (PRO == 1) { nw[p][0] = *(const float4*)(a.nw + k_lo + 8 * oc); nw[p][1] = *(const float4*)(a.nw + k_lo + 8 * oc + 4); }
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int o = o0 + oi + 64 * p;
+        float t[8] = {g[p][0].x, g[p][0].y, g[p][0].z, g[p][0].w, g[p][1].x, g[p][1].y, g[p][1].z, g[p][1].w};
+        if (PRO == 2) {  // silu(gate) * up
+          const float uu[8] = {u[p][0].x, u[p][0].y, u[p][0].z, u[p][0].w, u[p][1].x, u[p][1].y, u[p][1].z, u[p][1].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t[e] = t[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-t[e])) * uu[e];
+        } else if (PRO == 1) {
+          const float ww[8] = {nw[p][0].x, nw[p][0].y, nw[p][0].z, nw[p][0].w, nw[p][1].x, nw[p][1].y, nw[p][1].z, nw[p][1].w};
+          const float cnt = o < noct ? live : 0.0f;  // (a clamped duplicate of a ragged pass does not count)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ssq = __builtin_fmaf(t[e] * cnt, t[e], ssq); t[e] *= ww[e]; }
+        }
+        unsigned x1[4], x2[4], x3[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float a0 = t[e] * live, a1 = t[e + 1] * live;
+          const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+          const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+          x1[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);  // high halves: lower k in the low half
+          x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+          x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+        }
+        if (o < noct) {
+          char* d = dst0 + (o >> 2) * CHB + (o & 3) * KOP;
+          *(uint4*)d = make_uint4(x1[0], x1[1], x1[2], x1[3]);
+          *(uint4*)(d + 32) = make_uint4(x2[0], x2[1], x2[2], x2[3]);
+          *(uint4*)(d + FRAG) = make_uint4(x3[0], x3[1], x3[2], x3[3]);
+          *(uint4*)(d + FRAG + 32) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
+    if (PRO == 1) {
+      ssq += __shfl_xor(ssq, 8); ssq += __shfl_xor(ssq, 16); ssq += __shfl_xor(ssq, 32);
+      if (lane < 8) rsq[wave * 8 + lane] = ssq;  // (its own LDS words: visible behind the barriers below)
+    }
+  }
+  kk_f32x4 acc[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) acc[s] = kk_f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  {
+    const char* xl = xf + (lane >> 4) * KOP + (lane & 15) * 16;
+    const int rounds = (nch + 31) >> 5;
+#pragma unroll 1
+    for (int rd = 0; rd < rounds; ++rd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = wave + 8 * (4 * rd + j);
+        if (c < nch) {
+          const kk_bf16x8 a1 = *(const kk_bf16x8*)(xl + c * CHB), a2 = *(const kk_bf16x8*)(xl + c * CHB + FRAG);
+          kk_bf16x8 b[NSUB];
+#pragma unroll
+          for (int s = 0; s < NSUB; ++s) b[s] = __builtin_bit_cast(kk_bf16x8, ring[j][s]);
+          if (c + 32 < nch) {  // refill the slot for the next round
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)((c + 32) * NSUB + s) * 64);
+          }
+#pragma unroll
+          for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[s], acc[s], 0, 0, 0);
+#pragma unroll
+          for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[s], acc[s], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- the waves' partial tiles meet in LDS (wave order); lane L of sub-block s: rows 2 (L / 16) + j, column 16 s + L % 16
+  __syncthreads();  // xf is no longer read
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+    red[((wave * NSUB + s) * 2 + 0) * 64 + lane] = acc[s][0] + acc[s][2];
+    red[((wave * NSUB + s) * 2 + 1) * 64 + lane] = acc[s][1] + acc[s][3];
+  }
+  __syncthreads();
+  if (tid < NSUB * 128) {
+    const int s = tid >> 7, j = (tid >> 6) & 1;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[((w * NSUB + s) * 2 + j) * 64 + lane];
+    const int r = 2 * (lane >> 4) + j, n = nb * (16 * NSUB) + 16 * s + (lane & 15);
+    if (r < M && n < a.N) {
+      const long long mg = m0 + r;
+      if (PRO == 1) {
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q += rsq[w * 8 + r];
+        t *= 1.0f / sqrtf(q / (float)K + a.eps);
+      }
+      if (EPI == 1) t += a.res[mg * a.rrs + n];
+      if (EPI == 2) a.out[(long long)blockIdx.y * a.pss + mg * a.ors + n] = t;  // K slice blockIdx.y of a split-K launch
+      else a.out[mg * a.ors + n] = t;
+    }
+  }
+}
+static size_t gm_lds_bytes(int nsub, int kper) {
+  const size_t xb = (size_t)(kper / 32) * 2304, rb = (size_t)nsub * 4096;
+  return (xb > rb ? xb : rb) + 256;
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 struct Packer {
   kk_csm* m;
@@ -1147,6 +1332,27 @@ struct Packer {
             db[((size_t)(o / CB) * I + i) * CB + o % CB] = (uint16_t)(u >> 16);
           }
       }
+      if (I % 32 == 0 && !getenv("KK_CSM_NO_MFMA")) {
+        // fragment pack of gemvm_kernel.  Split-K for the deep projections (K >= 4096 in slices of 1024 rows), then the widest column
+        // block (16 * nsub) that still gives ~200 workgroups; both depend on the matrix only, never on the batch.
+        l.ks = (I >= 4096 && I % 1024 == 0) ? (I / 1024 > 16 ? 16 : I / 1024) : 1;
+        while (l.ks > 1 && (I % l.ks != 0 || (I / l.ks) % 32 != 0)) --l.ks;
+        const int nb16 = (O + 15) / 16;
+        l.nsub = nb16 * l.ks / 4 >= 192 ? 4 : (nb16 * l.ks / 2 >= 192 ? 2 : 1);
+        const int CBm = 16 * l.nsub, nblk = (O + CBm - 1) / CBm, nchunk = I / 32;
+        l.moff = m->packb.size();
+        m->packb.resize(l.moff + (size_t)nblk * I * CBm, 0);
+        uint16_t* dm = &m->packb[l.moff];
+        for (int i = 0; i < I; ++i) {
+          const int c = i >> 5, kq = (i & 31) >> 3, j = i & 7;
+          for (int o = 0; o < O; ++o) {
+            uint32_t u;
+            memcpy(&u, &dst[(size_t)i * l.ldw + o], 4);
+            const int nbk = o / CBm, sb = (o % CBm) >> 4, L = kq * 16 + (o & 15);
+            dm[((((size_t)nbk * nchunk + c) * l.nsub + sb) * 64 + L) * 8 + j] = (uint16_t)(u >> 16);
+          }
+        }
+      }
     }
     return l;
   }
@@ -1202,6 +1408,7 @@ void pack_stack(Packer& P, const std::string& name, Stack& st, int max_pos) {
 void resolve(kk_csm* m, Lin& l) {
   l.w = m->dev + l.off;
   l.wb = (m->devb && l.oct) ? m->devb + l.boff : nullptr;
+  l.wm = (m->devb && l.nsub) ? m->devb + l.moff : nullptr;
 }
 void resolve(kk_csm* m, Vec& v) { v.p = v.n ? m->dev + v.off : nullptr; }
 void resolve(kk_csm* m, Stack& st) {
@@ -1295,6 +1502,7 @@ struct Run {
 // fused GEMV launcher: `a` carries everything but the weights; rows in chunks of 16 (PRO 3: `rows` rows per item, chunk = whole items)
 // split-K slices of a deep projection (K >= 4096 on 64-column blocks): enough workgroups to fill the chip; depends on the matrix only
 int gemv_slices(const Lin& w) {
+  if (w.nsub) return w.ks;
   if (w.oct != 8 || w.Cin < 4096) return 1;
   const int nblk = (w.Cout + 63) / 64;
   int ks = 256 / nblk;
@@ -1302,7 +1510,45 @@ int gemv_slices(const Lin& w) {
   while (ks > 1 && (w.Cin % ks != 0 || (w.Cin / ks) % 32 != 0)) --ks;
   return ks < 1 ? 1 : ks;
 }
+// the matrix-core GEMV: one launch for all rows (grid z = 8-row chunks); KS must be the pack's w.ks
+int launch_gemvm(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st) {
+  a.w = w.wm; a.K = w.Cin; a.N = w.Cout; a.M = Mtot; a.dbg = 0;
+  const int CB = 16 * w.nsub, nblk = (w.Cout + CB - 1) / CB, kper = w.Cin / w.ks;
+  const size_t lds = gm_lds_bytes(w.nsub, kper);
+  if (lds > 160 * 1024) return kk_fail("kk_csm: internal: matrix-core GEMV: K slice too long for LDS");
+  if (pro == 3 && 8 % a.rows != 0) return kk_fail("kk_csm: internal: matrix-core GEMV: item rows");
+  const dim3 grid(nblk, w.ks, (Mtot + 7) / 8);
+#define GM_GO(NSUB, PRO, EPI)                                                                                                            \
+  do {                                                                                                                                   \
+    static KKDevOnce attr;                                                                                                               \
+    if (attr.first()) {                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)gemvm_kernel<NSUB, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+      attr.done();                                                                                                                       \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL((gemvm_kernel<NSUB, PRO, EPI>), grid, dim3(512), lds, st, a);                                                     \
+  } while (0)
+#define GM_PE(NSUB)                                                         \
+  do {                                                                       \
+    if (pro == 1 && epi == 0) GM_GO(NSUB, 1, 0);                             \
+    else if (pro == 0 && epi == 1) GM_GO(NSUB, 0, 1);                        \
+    else if (pro == 2 && epi == 1) GM_GO(NSUB, 2, 1);                        \
+    else if (pro == 2 && epi == 2) GM_GO(NSUB, 2, 2);                        \
+    else if (pro == 3 && epi == 0) GM_GO(NSUB, 3, 0);                        \
+    else if (pro == 0 && epi == 0) GM_GO(NSUB, 0, 0);                        \
+    else return kk_fail("kk_csm: internal: fused GEMV form");                \
+  } while (0)
+  if (w.nsub == 4) GM_PE(4); else if (w.nsub == 2) GM_PE(2); else GM_PE(1);
+#undef GM_PE
+#undef GM_GO
+  KK_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_gemv(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st, int KS = 1) {
+  if (w.wm && w.nsub) {
+    if (KS != w.ks || (epi == 2) != (w.ks > 1)) return kk_fail("kk_csm: internal: split-K form");
+    return launch_gemvm(w, pro, epi, a, Mtot, st);
+  }
   if (!w.wb || !w.oct) return kk_fail("kk_csm: internal: fused GEMV without a block pack");
   a.w = w.wb; a.K = w.Cin; a.N = w.Cout;
   {
