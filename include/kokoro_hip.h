@@ -323,6 +323,15 @@ int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, const int32_t* 
  * hipGraphLaunch (the backbone position is a device counter, so the captured step is position-independent); results are unchanged */
 int kk_csm_set_graph_mode(kk_csm* m, int on);
 int kk_csm_debug_logits(kk_csm* m, void* stream, int B, float* dst); /* logits of the last frame, [n_cb][B][audio_vocab] */
+/* TIMING ONLY (results are wrong while a bit is set): kernel classes of the single-token step that are not launched; process-wide.
+   bit 0 q|k|v, 1 attention, 2 o, 3 gate|up, 4 down, 5 split-K combine, 6 heads, 7 sampler, 8 projection (tools/csm_skip_sweep.py) */
+int kk_csm_debug_skip(int mask);
+/* In-kernel wall-clock marks (100 MHz counter) of the single-token step's instrumented kernels, 8 uint64 per launch in launch order:
+   class id, earliest workgroup start, latest workgroup end, workgroup 0 after its input loads, then workgroup 0's own start, shader-clock
+   count at start, end, shader-clock count at end (core clock = cycles / wall x 100 MHz).  buf: device memory for `capacity`
+   launches, the caller fills words 1 with ~0 and 2 with 0 before a frame; NULL switches the marks off.  Process-wide, debugging only
+   (tools/csm_timeline.py). */
+int kk_csm_debug_timestamps(unsigned long long* buf, int capacity);
 /* the sampler of generate_frame on its own (mlx_lm make_sampler(temp, top_k), sesame.py:335-336,719): logits [B][V] -> codes [B];
  * uniforms [B] or NULL (argmax).  Radix select of the top_k set + one-wave sort; V <= 8192. */
 int kk_op_csm_sample(void* stream, int B, int V, const float* logits, float temperature, int top_k, const float* uniforms, int32_t* codes_out);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "kk_csm_generate_frame": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "kk_csm_set_graph_mode": (_i, [_vp, _i]),
     "kk_csm_debug_logits": (_i, [_vp, _vp, _i, _vp]),
+    "kk_csm_debug_skip": (_i, [_i]),
+    "kk_csm_debug_timestamps": (_i, [_vp, _i]),
     "kk_op_csm_sample": (_i, [_vp, _i, _i, _vp, _f, _i, _vp, _vp]),
     "kk_mimi_create": (_i, [C.POINTER(KKMimiConfig), C.POINTER(_vp)]),
     "kk_mimi_destroy": (None, [_vp]),

@@ -21,8 +21,7 @@
 
 namespace {
 
-typedef float kk_f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 kk_bf16x8 __attribute__((ext_vector_type(8)));
+#include "kk_csm_gemvm.h"
 
 struct Lin {  // generic-kernel pack [1][Cin][ldw]
   size_t off = 0;
@@ -98,9 +97,20 @@ namespace {
 
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// kk_csm_debug_skip (TIMING ONLY, wrong results): kernel classes of the single-token step that are not launched -- bit 0 q|k|v, 1 attention,
+// 2 o, 3 gate|up, 4 down, 5 split-K combine, 6 heads, 7 sampler, 8 projection: the in-situ cost of a class is the frame time it removes
+int g_skip = 0;
+// kk_csm_debug_timestamps: in-kernel wall-clock marks (100 MHz) of the instrumented kernels, 8 words per launch in launch order:
+// [class id, earliest workgroup start, latest workgroup end, workgroup 0 after its input loads, workgroup 0's start / shader clock at start / end / shader
+// clock at end]; null in production
+unsigned long long* g_ts = nullptr;
+int g_ts_cap = 0, g_ts_next = 0;
+unsigned long long* ts_slot() { return (g_ts && g_ts_next < g_ts_cap) ? g_ts + 8 * (size_t)g_ts_next++ : nullptr; }
+int g_dbg = 0;  // bits 16..19 of the mask: phases of gemvm_kernel switched off (1 input staging, 2 matrix instructions, 4 reduction, 8 weight loads)
+
 // ------------------------------------------------------------------------------------------------------------- kernels
 // h[b][s][:] = sum_j mask[b][s][j] * emb_j(tokens[b][s][j]),  j < n_cb: audio_embeddings[token + j*V], j = n_cb: text_embeddings
-__global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const float* mask, const float* audio, const float* text, int ncb, int V,
+__global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const float* mask, const float* audio, const float* text, int ncb, int V, int TV,
                                                         int D, float* h) {
   const long long row = blockIdx.x;  // b*S + s
   const int* tk = tokens + row * (ncb + 1);
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const
   for (int c = threadIdx.x; c < D; c += 256) {
     float acc = 0.f;
     for (int j = 0; j <= ncb; ++j) {
-      const float* e = j < ncb ? audio + ((long long)tk[j] + (long long)j * V) * D : text + (long long)tk[j] * D;
+      const float* e = j < ncb ? audio + ((long long)clamp_id(tk[j], V) + (long long)j * V) * D : text + (long long)clamp_id(tk[j], TV) * D;
       acc += e[c] * mk[j];
     }
     h[row * D + c] = acc;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const
 __global__ __launch_bounds__(256) void embed_audio_kernel(const int* codes, int cstride, const float* audio, int cb, int V, int D, float* out, int rows,
                                                           int pos) {
   const int b = blockIdx.x;
-  const float* e = audio + ((long long)codes[(long long)b * cstride] + (long long)cb * V) * D;
+  const float* e = audio + ((long long)clamp_id(codes[(long long)b * cstride], V) + (long long)cb * V) * D;
   for (int c = threadIdx.x; c < D; c += 256) out[((long long)b * rows + pos) * D + c] = e[c];
 }
 
@@ -287,6 +297,127 @@ __global__ __launch_bounds__(128) void attn_cache_kernel(const float* qkv, int S
   }
 }
 
+// attn_step_kernel (round 3): the single-token attention over a SHORT cache (max_pos <= 64: the depth decoder's 33 positions, small test
+// stacks) as ONE memory round trip.  attn_cache_kernel walks the keys in dependent steps (a thread per key with 2 x 16 loads, then the
+// values 4 keys at a time): 7.6 us per launch in the frame (tools/csm_skip_sweep.py), 124 launches.  Here a workgroup owns one (item, kv
+// head) and its G = H / KV query heads: every cached K and V row, the new q / k / v and the RoPE row are requested at once, land in LDS
+// (K rows padded to hd + 4 floats: a lane per key reads 16-byte pieces without bank conflicts), and scores, softmax (a lane per key, one
+// wave per head) and the weighted sum run out of LDS.  RoPE of q / k and the cache append are fused as in attn_cache_kernel<true>.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_step_kernel(const float* qkv, int H, int KV, const int* pos_dev, int offset, float* kc, float* vc, int max_pos,
+                                                         float scale, float* out, const float* rope, const int* pad, unsigned long long* ts) {
+  constexpr int HD4 = HD / 4, KP = HD + 4;
+  extern __shared__ __attribute__((aligned(16))) float sma[];
+  ts_begin(ts, 1);
+  const int G = H / KV, kvh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* ks = sma;                   // [max_pos][KP]
+  float* vs = ks + max_pos * KP;     // [max_pos rounded up to 4][HD]
+  float* qs = vs + ((max_pos + 3) & ~3) * HD;  // [G][HD]
+  float* sc = qs + G * HD;           // [G][64]
+  float* inv = sc + G * 64;          // [G]
+  if (pos_dev) offset += *pos_dev;
+  const int pd = pad ? pad[b] : 0, nk = offset + 1 - pd;
+  const int W = (H + 2 * KV) * HD;
+  if (nk <= 0) {  // a padding row: no key, the output is defined as zero (nothing reads it)
+    for (int o = tid; o < G * HD; o += 256) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = 0.f;
+    return;
+  }
+  const float* kb = kc + ((long long)b * max_pos + pd) * KV * HD + kvh * HD;
+  const float* vb = vc + ((long long)b * max_pos + pd) * KV * HD + kvh * HD;
+  const int nold = (nk - 1) * HD4;  // float4 of the cached rows (<= 63 * 32)
+  float4 kr[8], vr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < nold) {
+      const int j = idx / HD4, e = idx - j * HD4;
+      kr[i] = *(const float4*)(kb + (long long)j * KV * HD + 4 * e);
+      vr[i] = *(const float4*)(vb + (long long)j * KV * HD + 4 * e);
+    }
+  }
+  {  // the new position: RoPE on q (G heads) and k, v as is; k / v also go to the cache
+    const float* cs = rope + (long long)(offset - pd) * (HD / 2) * 2;
+    const float* q = qkv + (long long)b * W + (long long)kvh * G * HD;
+    const float* kq = qkv + (long long)b * W + (H + kvh) * HD;
+    const float* vq = qkv + (long long)b * W + (H + KV + kvh) * HD;
+    float* kdst = kc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
+    float* vdst = vc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
+    for (int i = tid; i < G * (HD / 2); i += 256) {
+      const int ii = i % (HD / 2);
+      const float2 c = *(const float2*)(cs + 2 * ii), x = *(const float2*)(q + 2 * i);
+      *(float2*)(qs + 2 * i) = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
+    }
+    if (tid < HD / 2) {
+      const float2 c = *(const float2*)(cs + 2 * tid), x = *(const float2*)(kq + 2 * tid);
+      const float2 kn = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
+      *(float2*)(ks + (nk - 1) * KP + 2 * tid) = kn;
+      *(float2*)(kdst + 2 * tid) = kn;
+    } else if (tid >= 128 && tid < 128 + HD / 2) {
+      const int t = tid - 128;
+      const float2 v = *(const float2*)(vq + 2 * t);
+      *(float2*)(vs + (nk - 1) * HD + 2 * t) = v;
+      *(float2*)(vdst + 2 * t) = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < nold) {
+      const int j = idx / HD4, e = idx - j * HD4;
+      *(float4*)(ks + j * KP + 4 * e) = kr[i];
+      *(float4*)(vs + j * HD + 4 * e) = vr[i];
+    }
+  }
+  for (int i = tid; i < (((nk + 3) & ~3) - nk) * HD; i += 256) vs[nk * HD + i] = 0.f;  // V rows of the padded key count (weight exactly 0)
+  __syncthreads();
+  ts_mid(ts);
+  for (int p = tid >> 2; p < G * nk; p += 64) {  // (head, key) per 4 lanes: each lane a quarter of the head dimension, then two butterfly adds
+    const int g = p / nk, j = p - g * nk, qd = tid & 3;
+    const float4* kr4 = (const float4*)(ks + j * KP) + qd * (HD4 / 4);
+    const float4* q4 = (const float4*)(qs + g * HD) + qd * (HD4 / 4);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD4 / 4; e += 2) {
+      const float4 ka = kr4[e], qa = q4[e], kb2 = kr4[e + 1], qb = q4[e + 1];
+      d0 = __builtin_fmaf(qa.x, ka.x, d0); d0 = __builtin_fmaf(qa.y, ka.y, d0); d0 = __builtin_fmaf(qa.z, ka.z, d0); d0 = __builtin_fmaf(qa.w, ka.w, d0);
+      d1 = __builtin_fmaf(qb.x, kb2.x, d1); d1 = __builtin_fmaf(qb.y, kb2.y, d1); d1 = __builtin_fmaf(qb.z, kb2.z, d1); d1 = __builtin_fmaf(qb.w, kb2.w, d1);
+    }
+    float d = d0 + d1;
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    if (qd == 0) sc[g * 64 + j] = d * scale;
+  }
+  __syncthreads();
+  for (int g = wave; g < G; g += 4) {  // softmax of one head: a lane per key (nk <= 64)
+    const float v = lane < nk ? sc[g * 64 + lane] : -INFINITY;
+    float mx = v;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float pr = lane < nk ? expf(v - mx) : 0.f;
+    float sum = pr;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sc[g * 64 + lane] = pr;  // (lanes >= nk: exact zeros, so the weighted sum below may run over a padded key count)
+    if (lane == 0) inv[g] = 1.0f / sum;
+  }
+  __syncthreads();
+  const int nk4 = (nk + 3) & ~3;  // <= 64; the V rows behind nk are finite (stale or zero-filled below) and meet weight 0
+  for (int o = tid; o < G * HD; o += 256) {
+    const int g = o / HD, e = o - g * HD;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = 0; j < nk4; j += 4) {  // (four chains; key order inside each)
+      const float4 pw = *(const float4*)(sc + g * 64 + j);
+      a0 = __builtin_fmaf(pw.x, vs[j * HD + e], a0);
+      a1 = __builtin_fmaf(pw.y, vs[(j + 1) * HD + e], a1);
+      a2 = __builtin_fmaf(pw.z, vs[(j + 2) * HD + e], a2);
+      a3 = __builtin_fmaf(pw.w, vs[(j + 3) * HD + e], a3);
+    }
+    out[(long long)b * H * HD + (long long)kvh * G * HD + o] = ((a0 + a1) + (a2 + a3)) * inv[g];
+  }
+  ts_end(ts);
+}
+static size_t attn_step_lds_bytes(int max_pos, int hd, int G) {
+  return ((size_t)max_pos * (hd + 4) + (size_t)((max_pos + 3) & ~3) * hd + (size_t)G * hd + (size_t)G * 64 + 16) * 4;
+}
+
 // dynamic LDS of attn_cache_kernel: scores (padded to 4) + q + G partial outputs of hd floats (G = 512 / hd) + the new k and v rows
 static size_t attn_lds_bytes(int max_pos, int hd) { return ((size_t)((max_pos + 3) & ~3) + hd + (size_t)(512 / hd) * hd + 2 * hd) * 4; }
 
@@ -355,7 +486,7 @@ __device__ void sample_rounds(float (&v)[NPER], int V, float temp, int top_k, co
   if (tid == 0) {
     int pick = topi[0];
     if (!greedy) {
-      float c[64];
+      __shared__ float c[64];  // (LDS, not a private array: scratch memory would be set up for every dispatch of the kernel)
       const float z0 = topv[0] / temp;
       float run = 0.f;
       for (int r = 0; r < k; ++r) {
@@ -389,8 +520,6 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* logits,
   __shared__ unsigned s_prefix, s_krem, s_bin, ccount;
   __shared__ unsigned ckey[64];
   __shared__ int cidx[64];
-  __shared__ float topv[64], ev[64];
-  __shared__ int topi[64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned key[NPER];
 #pragma unroll
@@ -491,26 +620,26 @@ __global__ __launch_bounds__(256) void sample_select_kernel(const float* logits,
       const bool want_first = ((lane & stride) == 0) == ((lane & size) == 0 || size == 64);  // this lane keeps the earlier element
       if (other_first == want_first) { kk = ok; ii = oi; }
     }
-  if (lane < k) { topv[lane] = sk_unkey(kk); topi[lane] = ii; }
-  __builtin_amdgcn_wave_barrier();
-  if (!greedy && lane < k) ev[lane] = expf(topv[lane] / temp - topv[0] / temp);
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    int pick = topi[0];
-    if (!greedy) {
-      float c[64];
-      float run = 0.f;
-      for (int r = 0; r < k; ++r) {
-        run += ev[r];
-        c[r] = run;
-      }
-      const float target = u[(long long)b * ustride] * run;
-      int j = 0;
-      while (j < k - 1 && c[j] < target) ++j;
-      pick = topi[j];
+  // lane r holds the r-th candidate.  The cumulative sums run in candidate order (the oracle's cumsum) on values read lane by lane
+  // (v_readlane with a uniform index): the whole wave walks the same scalar chain, no scratch array, no LDS round trips
+  const float tv = sk_unkey(kk);
+  auto lane_f = [](float v, int l) __attribute__((always_inline)) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+  const float t0 = lane_f(tv, 0);
+  const float e = (!greedy && lane < k) ? expf(tv / temp - t0 / temp) : 0.f;
+  int pick = __builtin_amdgcn_readlane(ii, 0);
+  if (!greedy) {
+    float run = 0.f;
+    for (int r = 0; r < k; ++r) run += lane_f(e, r);
+    const float target = u[(long long)b * ustride] * run;
+    int j = 0;
+    float c = lane_f(e, 0);
+    while (j < k - 1 && c < target) {
+      ++j;
+      c += lane_f(e, j);
     }
-    out[(long long)b * ostride] = pick;
+    pick = __builtin_amdgcn_readlane(ii, __builtin_amdgcn_readfirstlane(j));
   }
+  if (lane == 0) out[(long long)b * ostride] = pick;
 }
 
 int launch_sample(const float* logits, int V, float temp, int top_k, const float* u, int ustride, int* out, int ostride, int B, hipStream_t st) {
@@ -637,20 +766,9 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* part, i
 //   * a weight meets all rows in packed fp32 FMAs (accumulators acc[8 columns][MT / 2 row pairs]); per lane the k order is fixed by the
 //     layout, so a row's bits do not depend on its batch neighbours or on MT;
 //   * the lanes' / waves' partial sums meet in LDS in a fixed order; EPI 1 adds the residual (h += ...) in place.
-struct FGArgs {
-  const float* x; long long xrs;   // input row m at x + m * xrs (PRO 2: 2K floats, gate | up)
-  const float* nw; float eps;      // PRO 1
-  const int* codes; int cstride, cb, V, rows; const float* emb;  // PRO 3: row m is item m / rows; its LAST row is emb[(codes[item * cstride] + cb * V)], others come from x
-  const uint16_t* w;
-  int K, N, M;
-  const float* res; long long rrs;  // EPI 1
-  float* out; long long ors;
-  long long pss;                    // EPI 2: floats between the partial tiles of consecutive K slices
-  int dbg;                          // KK_CSM_DBG (TIMING ONLY, wrong results): 1 no input staging, 2 no FMAs, 4 no reduction, 8 no weight loads
-};
-
 // h[m][n] += sum over the K slices of a split-K launch (slice order): the combine of the deep down projections
-__global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, int KS, long long pss, long long n, float* h) {
+__global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, int KS, long long pss, long long n, float* h, unsigned long long* ts) {
+  ts_begin(ts, 2);
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   // all slices are requested at once (a plain loop is KS dependent L2 round trips); KS <= 16 (gemv_slices)
@@ -662,6 +780,7 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const float* part, 
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) t += ks < KS ? v[ks] : 0.f;
   h[e] = h0 + t;
+  ts_end(ts);
 }
 
 // sum over the 32 lanes of a half wave (butterfly)
@@ -718,7 +837,7 @@ __global__ __launch_bounds__(256) void fused_gemv_kernel(FGArgs a) {
     if (PRO == 3) {
       const int item = mm / a.rows, r = mm - item * a.rows;
       rowemb[m] = r == a.rows - 1;
-      rowoff[m] = rowemb[m] ? (a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : (int)(item * a.xrs);
+      rowoff[m] = rowemb[m] ? (clamp_id(a.codes[(long long)item * a.cstride], a.V) + a.cb * a.V) * K : (int)(item * a.xrs);
     } else {
       rowoff[m] = (int)(mm * a.xrs);
     }
@@ -957,7 +1076,7 @@ __global__ __launch_bounds__(256) void gemv8_kernel(FGArgs a) {
     const float* row;
     if (PRO == 3) {  // an item's last row comes from the audio embedding table (sesame.py:373-392), its other rows from x
       const int item = mm / a.rows, r = mm - item * a.rows;
-      row = r == a.rows - 1 ? a.emb + (long long)(a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
+      row = r == a.rows - 1 ? a.emb + (long long)(clamp_id(a.codes[(long long)item * a.cstride], a.V) + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
     } else {
       row = a.x + (long long)mm * a.xrs;
     }
@@ -1074,181 +1193,6 @@ static size_t fg_lds_bytes() {
   return (xsb > redb ? xsb : redb) + (size_t)4 * (8 * OCT * 8) * 4 + 64 + 256;  // + rs [16] + the waves' sums of squares [4][16]
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// gemvm_kernel (round 3): the single-token product on the MATRIX CORES, with every weight byte of the workgroup requested up front.
-// What the per-kernel times of gemv8_kernel showed (profiles/r03_b_csm_bf16w_kernel_stats.csv): 15.5 us for gate|up (33.5 MB: 2.2 TB/s),
-// 8.7 us for q|k|v (3 MB), 7.3 us for o (2 MB), while a chain of EMPTY kernels costs 1.55 us per launch in graph replay
-// (tools/gridbar/launchfloor.hip): a frame is bound by the latency INSIDE its kernels.  gemv8 keeps 8 loads x 4 waves = 32 KB in flight
-// per CU, so gate|up's 128 KB per workgroup are four exposed HBM round trips, and its 64 fp32 accumulators per lane (8 columns x 8 rows)
-// leave no registers for a deeper ring and need a 3-stage LDS reduction.  Here:
-//   * x (fp32, after the prologue) is split EXACTLY into three bf16 terms by truncation, x = x1 + x2 + x3 (8 + 8 + 8 significand bits:
-//     x1 = top half of x, x2 = top half of x - x1, x3 = x - x1 - x2, all subtractions exact), and the bf16 weights meet them in
-//     v_mfma_f32_16x16x32_bf16: products of two bf16 are exact in fp32 and the instruction accumulates in fp32, so the result is an
-//     fp32-arithmetic dot product of the fp32 input with the bf16 matrix -- what the round-2 kernels computed with v_pk_fma_f32 -- in a
-//     different summation order.  A (16 m x 32 k) carries the terms: m slot 4 (r / 2) + 2 t + r % 2 = term t of input row r, first
-//     instruction [x1 | x2], second [x3 | 0]; B (32 k x 16 n) is one 1-KiB wave load of the fragment pack.  A lane of the 16 x 16 result
-//     holds rows 2 g, 2 g + 1 (g = lane / 16) of column lane % 16 as acc[0] + acc[2], acc[1] + acc[3]: 4 accumulator registers per 16
-//     columns instead of 64, no cross-lane reduction at all, one 4-KiB-per-16-columns exchange between the 8 waves at the end.
-//     A row's result does not depend on the other rows of the launch (an output element of the instruction reads its own A row only).
-//   * 512 threads; wave w owns the 32-row K chunks w, w + 8, ... and all NSUB 16-column sub-blocks of them: 4 chunks x NSUB loads of
-//     16 bytes per lane go out BEFORE the input is staged (K = 1024, 64 columns: the whole 128 KB of the workgroup at once), later
-//     rounds (K = 2048) refill a slot as it is consumed.
-//   * staging: thread (row r = tid % 8, octet tid / 8 + 64 p) loads 8 consecutive k of its row, applies the prologue, splits, and writes
-//     four 16-byte A operands; the k-octet pitch inside a fragment is 288 bytes, so the 8 rows x 2 octets of a 16-lane group cover all
-//     64 banks once (the rows' m slots leave 32-byte holes that the next octet fills), and the MFMA-side read of 16 lanes is 256
-//     contiguous bytes.  LDS: 2304 bytes per 32 k (72 KB for K = 1024, 144 KB for K = 2048).
-//   * RMSNorm: sum of squares per row while staging (fixed order: lane butterfly, then waves 0..7), scale applied to the finished dot
-//     products; EPI as before.  grid = (column blocks, K slices, 8-row chunks of M).
-template <int NSUB, int PRO, int EPI>
-__global__ __launch_bounds__(512) void gemvm_kernel(FGArgs a) {
-  constexpr int KOP = 288, FRAG = 4 * KOP, CHB = 2 * FRAG;
-  extern __shared__ __attribute__((aligned(16))) char smc[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = blockIdx.x, K = a.K;
-  const int Kper = K / gridDim.y, k_lo = blockIdx.y * Kper;
-  const int nch = Kper >> 5;
-  const int m0 = blockIdx.z * 8;
-  const int M = a.M - m0 < 8 ? a.M - m0 : 8;
-  const int mainb = nch * CHB > NSUB * 4096 ? nch * CHB : NSUB * 4096;
-  char* xf = smc;                           // [nch][2 fragments][4 k octets at pitch 288][16 m slots][8 bf16]
-  float* red = (float*)smc;                 // [8 waves][NSUB][2][64] (aliases xf after the main loop)
-  float* rsq = (float*)(smc + mainb);       // [8 waves][8 rows] sums of squares (PRO 1)
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4* wblk = (const u32x4*)a.w + ((long long)nb * (K >> 5) + (k_lo >> 5)) * (NSUB * 64) + lane;  // chunk c, sub-block s at + (c NSUB + s) 64
-  // ---- the first round of weight loads goes out before anything else
-  u32x4 ring[4][NSUB];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = wave + 8 * j;
-    if (c < nch) {
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)(c * NSUB + s) * 64);
-    }
-  }
-  // ---- stage the input rows: prologue, exact three-way bf16 split, fragment order
-  {
-    const int r = tid & 7, oi = tid >> 3, mg = m0 + (r < M ? r : 0);
-    const float* row;
-    if (PRO == 3) {  // an item's last row comes from the audio embedding table (sesame.py:373-392), its other rows from x
-      const int item = mg / a.rows, rr = mg - item * a.rows;
-      row = rr == a.rows - 1 ? a.emb + (long long)(a.codes[(long long)item * a.cstride] + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
-    } else {
-      row = a.x + (long long)mg * a.xrs;
-    }
-    row += k_lo;
-    const float live = r < M ? 1.0f : 0.0f;
-    const int noct = Kper >> 3;
-    float ssq = 0.f;
-    char* dst0 = xf + (4 * (r >> 1) + (r & 1)) * 16;
-    for (int o0 = 0; o0 < noct; o0 += 128) {  // two octets per thread in flight (K = 1024: one pass)
-      float4 g[2][2], u[PRO == 2 ? 2 : 1][2], nw[PRO == 1 ? 2 : 1][2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int o = o0 + oi + 64 * p, oc = o < noct ? o : 0;
-        g[p][0] = *(const float4*)(row + 8 * oc); g[p][1] = *(const float4*)(row + 8 * oc + 4);
-        if (PRO == 2) { u[p][0] = *(const float4*)(row + K + 8 * oc); u[p][1] = *(const float4*)(row + K + 8 * oc + 4); }
-        if (PRO == 1) { nw[p][0] = *(const float4*)(a.nw + k_lo + 8 * oc); nw[p][1] = *(const float4*)(a.nw + k_lo + 8 * oc + 4); }
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int o = o0 + oi + 64 * p;
-        float t[8] = {g[p][0].x, g[p][0].y, g[p][0].z, g[p][0].w, g[p][1].x, g[p][1].y, g[p][1].z, g[p][1].w};
-        if (PRO == 2) {  // silu(gate) * up
-          const float uu[8] = {u[p][0].x, u[p][0].y, u[p][0].z, u[p][0].w, u[p][1].x, u[p][1].y, u[p][1].z, u[p][1].w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) t[e] = t[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-t[e])) * uu[e];
-        } else if (PRO == 1) {
-          const float ww[8] = {nw[p][0].x, nw[p][0].y, nw[p][0].z, nw[p][0].w, nw[p][1].x, nw[p][1].y, nw[p][1].z, nw[p][1].w};
-          const float cnt = o < noct ? live : 0.0f;  // (a clamped duplicate of a ragged pass does not count)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { ssq = __builtin_fmaf(t[e] * cnt, t[e], ssq); t[e] *= ww[e]; }
-        }
-        unsigned x1[4], x2[4], x3[4];
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const float a0 = t[e] * live, a1 = t[e + 1] * live;
-          const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
-          const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
-          x1[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);  // high halves: lower k in the low half
-          x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
-          x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
-        }
-        if (o < noct) {
-          char* d = dst0 + (o >> 2) * CHB + (o & 3) * KOP;
-          *(uint4*)d = make_uint4(x1[0], x1[1], x1[2], x1[3]);
-          *(uint4*)(d + 32) = make_uint4(x2[0], x2[1], x2[2], x2[3]);
-          *(uint4*)(d + FRAG) = make_uint4(x3[0], x3[1], x3[2], x3[3]);
-          *(uint4*)(d + FRAG + 32) = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-    }
-    if (PRO == 1) {
-      ssq += __shfl_xor(ssq, 8); ssq += __shfl_xor(ssq, 16); ssq += __shfl_xor(ssq, 32);
-      if (lane < 8) rsq[wave * 8 + lane] = ssq;  // (its own LDS words: visible behind the barriers below)
-    }
-  }
-  kk_f32x4 acc[NSUB];
-#pragma unroll
-  for (int s = 0; s < NSUB; ++s) acc[s] = kk_f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  {
-    const char* xl = xf + (lane >> 4) * KOP + (lane & 15) * 16;
-    const int rounds = (nch + 31) >> 5;
-#pragma unroll 1
-    for (int rd = 0; rd < rounds; ++rd) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = wave + 8 * (4 * rd + j);
-        if (c < nch) {
-          const kk_bf16x8 a1 = *(const kk_bf16x8*)(xl + c * CHB), a2 = *(const kk_bf16x8*)(xl + c * CHB + FRAG);
-          kk_bf16x8 b[NSUB];
-#pragma unroll
-          for (int s = 0; s < NSUB; ++s) b[s] = __builtin_bit_cast(kk_bf16x8, ring[j][s]);
-          if (c + 32 < nch) {  // refill the slot for the next round
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)((c + 32) * NSUB + s) * 64);
-          }
-#pragma unroll
-          for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[s], acc[s], 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < NSUB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b[s], acc[s], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // ---- the waves' partial tiles meet in LDS (wave order); lane L of sub-block s: rows 2 (L / 16) + j, column 16 s + L % 16
-  __syncthreads();  // xf is no longer read
-#pragma unroll
-  for (int s = 0; s < NSUB; ++s) {
-    red[((wave * NSUB + s) * 2 + 0) * 64 + lane] = acc[s][0] + acc[s][2];
-    red[((wave * NSUB + s) * 2 + 1) * 64 + lane] = acc[s][1] + acc[s][3];
-  }
-  __syncthreads();
-  if (tid < NSUB * 128) {
-    const int s = tid >> 7, j = (tid >> 6) & 1;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += red[((w * NSUB + s) * 2 + j) * 64 + lane];
-    const int r = 2 * (lane >> 4) + j, n = nb * (16 * NSUB) + 16 * s + (lane & 15);
-    if (r < M && n < a.N) {
-      const long long mg = m0 + r;
-      if (PRO == 1) {
-        float q = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) q += rsq[w * 8 + r];
-        t *= 1.0f / sqrtf(q / (float)K + a.eps);
-      }
-      if (EPI == 1) t += a.res[mg * a.rrs + n];
-      if (EPI == 2) a.out[(long long)blockIdx.y * a.pss + mg * a.ors + n] = t;  // K slice blockIdx.y of a split-K launch
-      else a.out[mg * a.ors + n] = t;
-    }
-  }
-}
-static size_t gm_lds_bytes(int nsub, int kper) {
-  const size_t xb = (size_t)(kper / 32) * 2304, rb = (size_t)nsub * 4096;
-  return (xb > rb ? xb : rb) + 256;
-}
 
 // ------------------------------------------------------------------------------------------------------------- host
 struct Packer {
@@ -1512,20 +1456,28 @@ int gemv_slices(const Lin& w) {
 }
 // the matrix-core GEMV: one launch for all rows (grid z = 8-row chunks); KS must be the pack's w.ks
 int launch_gemvm(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st) {
-  a.w = w.wm; a.K = w.Cin; a.N = w.Cout; a.M = Mtot; a.dbg = 0;
+  a.w = w.wm; a.K = w.Cin; a.N = w.Cout; a.M = Mtot; a.dbg = g_dbg; a.kper = w.Cin / w.ks;
+  a.ts = ts_slot(); a.ts_id = (w.Cout << 4) | (pro << 2) | epi;
   const int CB = 16 * w.nsub, nblk = (w.Cout + CB - 1) / CB, kper = w.Cin / w.ks;
   const size_t lds = gm_lds_bytes(w.nsub, kper);
-  if (lds > 160 * 1024) return kk_fail("kk_csm: internal: matrix-core GEMV: K slice too long for LDS");
+  if (lds > 160 * 1024 || kper / 32 > 96) return kk_fail("kk_csm: internal: matrix-core GEMV: K slice too long for LDS");
   if (pro == 3 && 8 % a.rows != 0) return kk_fail("kk_csm: internal: matrix-core GEMV: item rows");
   const dim3 grid(nblk, w.ks, (Mtot + 7) / 8);
-#define GM_GO(NSUB, PRO, EPI)                                                                                                            \
+  const int rounds = (kper / 32 + 31) / 32;  // straight-line rounds of 4 chunks x 8 waves (K slice <= 1024: one)
+#define GM_GO1(NSUB, PRO, EPI, RD)                                                                                                       \
   do {                                                                                                                                   \
     static KKDevOnce attr;                                                                                                               \
     if (attr.first()) {                                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)gemvm_kernel<NSUB, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+      (void)hipFuncSetAttribute((const void*)gemvm_kernel<NSUB, PRO, EPI, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
       attr.done();                                                                                                                       \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((gemvm_kernel<NSUB, PRO, EPI>), grid, dim3(512), lds, st, a);                                                     \
+    hipLaunchKernelGGL((gemvm_kernel<NSUB, PRO, EPI, RD>), grid, dim3(512), lds, st, a);                                                 \
+  } while (0)
+#define GM_GO(NSUB, PRO, EPI)                                              \
+  do {                                                                      \
+    if (rounds == 1) GM_GO1(NSUB, PRO, EPI, 1);                             \
+    else if (rounds == 2) GM_GO1(NSUB, PRO, EPI, 2);                        \
+    else GM_GO1(NSUB, PRO, EPI, 3);                                         \
   } while (0)
 #define GM_PE(NSUB)                                                         \
   do {                                                                       \
@@ -1540,6 +1492,7 @@ int launch_gemvm(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t
   if (w.nsub == 4) GM_PE(4); else if (w.nsub == 2) GM_PE(2); else GM_PE(1);
 #undef GM_PE
 #undef GM_GO
+#undef GM_GO1
   KK_CHECK_LAUNCH();
   return 0;
 }
@@ -1725,8 +1678,24 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
     FGArgs g;
     memset(&g, 0, sizeof g);
     g.x = h; g.xrs = D; g.nw = L.n1.p; g.eps = a.rms_eps; g.out = qkv; g.ors = W;
-    CS_TRY(launch_gemv(L.qkv, 1, 0, g, M, r.st));
-    if (rows == 1) {
+    if (!(g_skip & 1)) CS_TRY(launch_gemv(L.qkv, 1, 0, g, M, r.st));
+    if (g_skip & 2) {
+    } else if (rows == 1 && st.max_pos <= 64 && H / KV <= 8 && !getenv("KK_CSM_OLD_ATTN")) {
+      const size_t lds = attn_step_lds_bytes(st.max_pos, hd, H / KV);
+      static KKDevOnce attr;
+      if (attr.first()) {
+        (void)hipFuncSetAttribute((const void*)attn_step_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_step_lds_bytes(64, 128, 8));
+        (void)hipFuncSetAttribute((const void*)attn_step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_step_lds_bytes(64, 64, 8));
+        attr.done();
+      }
+      if (hd == 128)
+        hipLaunchKernelGGL(attn_step_kernel<128>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, ts_slot());
+      else
+        hipLaunchKernelGGL(attn_step_kernel<64>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, ts_slot());
+      KK_CHECK_LAUNCH();
+    } else if (rows == 1) {
       hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(1, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, 1, H, KV, hd, st.pos_dev,
                          st.pos_dev ? 0 : offset, kc, vc, st.max_pos, 1.0f / sqrtf((float)hd), att, 1, -1, st.rope.p, st.pad_dev);
       KK_CHECK_LAUNCH();
@@ -1740,21 +1709,23 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
     }
     memset(&g, 0, sizeof g);
     g.x = att; g.xrs = (long long)H * hd; g.res = h; g.rrs = D; g.out = h; g.ors = D;
-    CS_TRY(launch_gemv(L.o, 0, 1, g, M, r.st));
+    if (!(g_skip & 4)) CS_TRY(launch_gemv(L.o, 0, 1, g, M, r.st));
     memset(&g, 0, sizeof g);
     g.x = h; g.xrs = D; g.nw = L.n2.p; g.eps = a.rms_eps; g.out = gu; g.ors = 2 * I;
-    CS_TRY(launch_gemv(L.gu, 1, 0, g, M, r.st));
+    if (!(g_skip & 8)) CS_TRY(launch_gemv(L.gu, 1, 0, g, M, r.st));
     memset(&g, 0, sizeof g);
     const int KS = gemv_slices(L.down);
     if (KS > 1) {  // deep projection: K slices over workgroups, then one small combine (h += sum of the slices)
       g.x = gu; g.xrs = 2 * I; g.out = part; g.ors = D; g.pss = (long long)M * D;
-      CS_TRY(launch_gemv(L.down, 2, 2, g, M, r.st, KS));
+      if (!(g_skip & 16)) CS_TRY(launch_gemv(L.down, 2, 2, g, M, r.st, KS));
       const long long n = (long long)M * D;
-      hipLaunchKernelGGL(combine_slices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, part, KS, n, n, h);
-      KK_CHECK_LAUNCH();
+      if (!(g_skip & 32)) {
+        hipLaunchKernelGGL(combine_slices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, part, KS, n, n, h, ts_slot());
+        KK_CHECK_LAUNCH();
+      }
     } else {
       g.x = gu; g.xrs = 2 * I; g.res = h; g.rrs = D; g.out = h; g.ors = D;
-      CS_TRY(launch_gemv(L.down, 2, 1, g, M, r.st));
+      if (!(g_skip & 16)) CS_TRY(launch_gemv(L.down, 2, 1, g, M, r.st));
     }
   }
   return 0;
@@ -1777,7 +1748,7 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   }
   if (r.oom) return kk_fail("kk_csm_generate_frame: workspace too small");
   if (!r.dry) {
-    hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, D, h);
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, c.text_vocab_size, D, h);
     KK_CHECK_LAUNCH();
   }
   const size_t inner = r.used;
@@ -1808,8 +1779,8 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
       FGArgs g;
       memset(&g, 0, sizeof g);
       g.x = last_h; g.xrs = last_rs; g.out = logits; g.ors = V;
-      CS_TRY(launch_gemv(m->c0_head, 0, 0, g, B, r.st));
-      CS_TRY(launch_sample(logits, V, temp, top_k, uniforms, ncb, codes, ncb, B, r.st));
+      if (!(g_skip & 64)) CS_TRY(launch_gemv(m->c0_head, 0, 0, g, B, r.st));
+      if (!(g_skip & 128)) CS_TRY(launch_sample(logits, V, temp, top_k, uniforms, ncb, codes, ncb, B, r.st));
     }
     int rows = 2, dpos = 0;
     for (int i = 1; i < ncb; ++i) {
@@ -1820,7 +1791,7 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
         memset(&g, 0, sizeof g);
         g.x = last_h; g.xrs = last_rs; g.codes = codes + (i - 1); g.cstride = ncb; g.cb = i - 1; g.V = V; g.rows = rows; g.emb = m->audio_emb.p;
         g.out = pin; g.ors = Dd;
-        CS_TRY(launch_gemv(m->proj, 3, 0, g, B * rows, r.st));
+        if (!(g_skip & 256)) CS_TRY(launch_gemv(m->proj, 3, 0, g, B * rows, r.st));
       }
       CS_TRY(stack_step(r, m->dec, pin, rows, dpos));
       if (r.used > peak) peak = r.used;
@@ -1830,8 +1801,8 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
         FGArgs g;
         memset(&g, 0, sizeof g);
         g.x = pin + (size_t)(rows - 1) * Dd; g.xrs = (long long)rows * Dd; g.nw = m->dec.norm.p; g.eps = c.decoder.rms_eps; g.out = logits; g.ors = V;
-        CS_TRY(launch_gemv(m->audio_head[i - 1], 1, 0, g, B, r.st));
-        CS_TRY(launch_sample(logits, V, temp, top_k, uniforms ? uniforms + i : nullptr, ncb, codes + i, ncb, B, r.st));
+        if (!(g_skip & 64)) CS_TRY(launch_gemv(m->audio_head[i - 1], 1, 0, g, B, r.st));
+        if (!(g_skip & 128)) CS_TRY(launch_sample(logits, V, temp, top_k, uniforms ? uniforms + i : nullptr, ncb, codes + i, ncb, B, r.st));
       }
       rows = 1;
     }
@@ -2113,7 +2084,7 @@ extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, cons
     memcpy(&tbits, &temperature, 4);
     const std::vector<unsigned long long> key = {(unsigned long long)B, (unsigned long long)(uintptr_t)tokens, (unsigned long long)(uintptr_t)tokens_mask,
         (unsigned long long)tbits, (unsigned long long)top_k, (unsigned long long)(uintptr_t)uniforms, (unsigned long long)(uintptr_t)workspace,
-        (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)codes_out};
+        (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)codes_out, (unsigned long long)(g_skip | g_dbg << 16), (unsigned long long)(uintptr_t)g_ts};
     kk_csm::GraphEntry* ge = nullptr;
     for (auto& g : m->graphs)
       if (g.key == key) ge = &g;
@@ -2157,6 +2128,19 @@ extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, cons
   }
   if (rc == 0) m->bb.offset += S;
   return rc;
+}
+
+extern "C" int kk_csm_debug_timestamps(unsigned long long* buf, int capacity) {
+  g_ts = buf;
+  g_ts_cap = buf ? capacity : 0;
+  g_ts_next = 0;
+  return 0;
+}
+
+extern "C" int kk_csm_debug_skip(int mask) {
+  g_skip = mask & 0xffff;
+  g_dbg = (mask >> 16) & 15;
+  return 0;
 }
 
 extern "C" int kk_csm_set_graph_mode(kk_csm* m, int on) {
