@@ -305,7 +305,7 @@ def bench_csm(args, rank, world):
                    "global_batch": B * world, "parallelism": f"replicas x{world}"},
         "ms_per_frame": ms_frame, "frames_per_step": FRAMES, "jobs_in_flight": NS,
         "ms_per_step_one_job_in_flight": (dt_one / args.steps * 1e3) if dt_one is not None else None,
-        "roofline": {"bound": "hbm", "kernel": "CSM frame step (five launches per Llama layer on fused_gemv_kernel; 16 + 31 x 4 layer passes)",
+        "roofline": {"bound": "hbm", "kernel": "CSM frame step (six launches per Llama layer, Linears on gemvm_kernel (matrix cores); 16 + 31 x 4 layer passes)",
                      "achieved": bytes_frame / (ms_frame * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": bytes_frame / (ms_frame * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
                      "bytes_per_frame": bytes_frame, "note": "algorithmic bytes = every Linear matrix a frame multiplies by, in bf16; one launch = one frame step "

@@ -38,6 +38,7 @@ struct Lin {  // generic-kernel pack [1][Cin][ldw]
   const uint16_t* wm = nullptr;
   int nsub = 0;  // 0 = no fragment pack (K not a multiple of 32)
   int ks = 1;    // split-K slices of a deep projection (K >= 4096): partial tiles + combine
+  int cached = 0;  // 1: plain (cacheable) weight loads instead of nontemporal ones
 };
 struct Vec {
   size_t off = 0;
@@ -106,7 +107,6 @@ int g_skip = 0;
 unsigned long long* g_ts = nullptr;
 int g_ts_cap = 0, g_ts_next = 0;
 unsigned long long* ts_slot() { return (g_ts && g_ts_next < g_ts_cap) ? g_ts + 8 * (size_t)g_ts_next++ : nullptr; }
-int g_dbg = 0;  // bits 16..19 of the mask: phases of gemvm_kernel switched off (1 input staging, 2 matrix instructions, 4 reduction, 8 weight loads)
 
 // ------------------------------------------------------------------------------------------------------------- kernels
 // h[b][s][:] = sum_j mask[b][s][j] * emb_j(tokens[b][s][j]),  j < n_cb: audio_embeddings[token + j*V], j = n_cb: text_embeddings
@@ -1194,6 +1194,119 @@ static size_t fg_lds_bytes() {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// gemmp_kernel (round 3): the PROMPT block's Linear layers (M = B x S rows, hundreds to thousands) on the matrix cores, from the same bf16
+// fragment pack and with the same exact three-way bf16 split of the fp32 input as gemvm_kernel -- out[M][N] = x[M][K] W (+ res) in
+// fp32 arithmetic on bf16 weights.  Round 2 ran the prompt through the library's generic fp32 conv kernel (64 launches, 37 ms for a
+// 64-token prompt at B = 8).  A workgroup (4 waves) owns 128 rows x 64 columns (four 16-column sub-blocks, whatever the pack's nsub) and
+// walks K in 32-row chunks: the A operands of a chunk (8 row tiles x 3 terms x 1 KiB) are split on the way from global memory into a
+// double-buffered LDS tile while the matrix instructions of the previous chunk run; wave w multiplies row tiles 2w, 2w + 1 with all four
+// B fragments (16-byte loads, one chunk ahead).  The three terms of a row accumulate into the SAME accumulator (x1 W + x2 W + x3 W), so a
+// row's result depends on nothing but its own input row: the prompt block is batch-invariant.
+struct GPArgs {
+  const float* x; long long xrs;
+  const uint16_t* w;
+  int K, N, M, nsub;
+  const float* res; long long rrs;
+  float* out; long long ors;
+};
+__global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 abuf[2][8 * 3 * 64];  // [buffer][row tile][term][k octet x 16 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 128, sb0 = blockIdx.x * 4, nch = a.K >> 5;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // B fragment of (chunk c, global sub-block sb): block sb / nsub, sub sb % nsub of the pack [block][chunk][sub][lane]
+  const int nsbt = (a.N + 15) >> 4;
+  const u32x4* bp[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int sb = sb0 + s < nsbt ? sb0 + s : nsbt - 1;  // (a sub-block past the end repeats the last one; its columns are not stored)
+    bp[s] = (const u32x4*)a.w + ((long long)(sb / a.nsub) * nch * a.nsub + sb % a.nsub) * 64 + lane;
+  }
+  const long long bstep = (long long)a.nsub * 64;  // per chunk
+  // A staging: thread (row tile tid / 64 (+ 4), k octet (tid / 16) % 4, row tid % 16) takes 8 consecutive k of its row
+  const int ar = tid & 15, ako = (tid >> 4) & 3, amt = tid >> 6;
+  const float* arow[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = m0 + (amt + 4 * it) * 16 + ar;
+    arow[it] = a.x + (long long)(row < a.M ? row : a.M - 1) * a.xrs + ako * 8;
+  }
+  float4 g[2][2];
+  u32x4 b[4], bn[4];
+  auto load_a = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { g[it][0] = *(const float4*)(arow[it] + 32 * c); g[it][1] = *(const float4*)(arow[it] + 32 * c + 4); }
+  };
+  auto store_a = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const float t[8] = {g[it][0].x, g[it][0].y, g[it][0].z, g[it][0].w, g[it][1].x, g[it][1].y, g[it][1].z, g[it][1].w};
+      unsigned x1[4], x2[4], x3[4];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float a0 = t[e], a1 = t[e + 1];
+        const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+        const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+        x1[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+        x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+        x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+      }
+      uint4* d = &abuf[buf][((amt + 4 * it) * 3) * 64 + ako * 16 + ar];
+      d[0] = make_uint4(x1[0], x1[1], x1[2], x1[3]);
+      d[64] = make_uint4(x2[0], x2[1], x2[2], x2[3]);
+      d[128] = make_uint4(x3[0], x3[1], x3[2], x3[3]);
+    }
+  };
+  kk_f32x4 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[mi][s] = kk_f32x4{0.f, 0.f, 0.f, 0.f};
+  load_a(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b[s] = *bp[s];
+  store_a(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    if (more) {
+      load_a(c + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bn[s] = *(bp[s] + (long long)(c + 1) * bstep);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const kk_bf16x8 af = __builtin_bit_cast(kk_bf16x8, abuf[c & 1][((2 * wave + mi) * 3 + t) * 64 + lane]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[mi][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(kk_bf16x8, b[s]), acc[mi][s], 0, 0, 0);
+      }
+    if (more) {
+      store_a((c + 1) & 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = bn[s];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int n = (sb0 + s) * 16 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long row = m0 + (2 * wave + mi) * 16 + 4 * (lane >> 4) + i;
+        if (row < a.M && n < a.N) {
+          float v = acc[mi][s][i];
+          if (a.res) v += a.res[row * a.rrs + n];
+          a.out[row * a.ors + n] = v;
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------- host
 struct Packer {
   kk_csm* m;
@@ -1426,6 +1539,21 @@ struct Run {
         return 0;
       }
     }
+    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && w.wm && w.nsub && !gated && rows > 2 && !getenv("KK_CSM_PROMPT_F32")) {
+      // the prompt block in bf16 weight mode: matrix cores (gemmp_kernel); KK_CSM_PROMPT_F32=1 keeps the round-2 generic fp32 kernel (A/B).
+      // The choice depends on the rows PER ITEM only, never on B: a stream's bits do not depend on its batch.
+      GPArgs g;
+      memset(&g, 0, sizeof g);
+      g.x = x; g.xrs = w.Cin; g.w = w.wm; g.K = w.Cin; g.N = w.Cout; g.M = B * rows; g.nsub = w.nsub;
+      g.res = res; g.rrs = w.Cout; g.out = out; g.ors = w.Cout;
+      hipLaunchKernelGGL(gemmp_kernel, dim3((w.Cout + 63) / 64, (g.M + 127) / 128), dim3(256), 0, st, g);
+      KK_CHECK_LAUNCH();
+      if (xn) {
+        hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * rows), dim3(256), 0, st, out, nw, w.Cout, eps, xn);
+        KK_CHECK_LAUNCH();
+      }
+      return 0;
+    }
     if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout) {
       // items are contiguous: one launch over B*rows rows, so a weight tile is read once for the whole batch (single-token steps would
       // otherwise re-read every matrix once per item)
@@ -1456,7 +1584,7 @@ int gemv_slices(const Lin& w) {
 }
 // the matrix-core GEMV: one launch for all rows (grid z = 8-row chunks); KS must be the pack's w.ks
 int launch_gemvm(const Lin& w, int pro, int epi, FGArgs a, int Mtot, hipStream_t st) {
-  a.w = w.wm; a.K = w.Cin; a.N = w.Cout; a.M = Mtot; a.dbg = g_dbg; a.kper = w.Cin / w.ks;
+  a.w = w.wm; a.K = w.Cin; a.N = w.Cout; a.M = Mtot; a.dbg = w.cached; a.kper = w.Cin / w.ks;
   a.ts = ts_slot(); a.ts_id = (w.Cout << 4) | (pro << 2) | epi;
   const int CB = 16 * w.nsub, nblk = (w.Cout + CB - 1) / CB, kper = w.Cin / w.ks;
   const size_t lds = gm_lds_bytes(w.nsub, kper);
@@ -1971,6 +2099,17 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
       for (int i = 0; i < ncb - 1; ++i) m->audio_head[i] = P.linear({}, {V}, Dd, ah->data() + (size_t)i * Dd * V);  // [Dd][V] used as x @ W
   }
   if (!P.err.empty()) return kk_fail(("kk_csm_finalize: " + P.err).c_str());
+  {  // KK_CSM_NT (A/B, measured equal within noise: 5.62 ms per frame each): "all" (default) nontemporal weight loads everywhere, "none" plain loads, "bb": the backbone
+    // streams and the depth decoder (222 MB re-read 31 times per frame, inside the reach of the 256-MB memory-side cache) is cacheable
+    const char* e = getenv("KK_CSM_NT");
+    const std::string mode = e ? e : "all";
+    const int dec_cached = mode != "all", bb_cached = mode == "none";
+    for (auto& L : m->dec.layers) L.qkv.cached = L.o.cached = L.gu.cached = L.down.cached = dec_cached;
+    for (auto& L : m->bb.layers) L.qkv.cached = L.o.cached = L.gu.cached = L.down.cached = bb_cached;
+    for (auto& l : m->audio_head) l.cached = dec_cached;
+    m->proj.cached = dec_cached;
+    m->c0_head.cached = bb_cached;
+  }
   if (hipMalloc((void**)&m->dev, m->pack.size() * sizeof(float)) != hipSuccess) return kk_fail("kk_csm_finalize: hipMalloc failed");
   if (hipMemcpyAsync(m->dev, m->pack.data(), m->pack.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
     return kk_fail("kk_csm_finalize: upload failed");
@@ -2084,7 +2223,7 @@ extern "C" int kk_csm_generate_frame(kk_csm* m, void* stream, int B, int S, cons
     memcpy(&tbits, &temperature, 4);
     const std::vector<unsigned long long> key = {(unsigned long long)B, (unsigned long long)(uintptr_t)tokens, (unsigned long long)(uintptr_t)tokens_mask,
         (unsigned long long)tbits, (unsigned long long)top_k, (unsigned long long)(uintptr_t)uniforms, (unsigned long long)(uintptr_t)workspace,
-        (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)codes_out, (unsigned long long)(g_skip | g_dbg << 16), (unsigned long long)(uintptr_t)g_ts};
+        (unsigned long long)workspace_bytes, (unsigned long long)(uintptr_t)codes_out, (unsigned long long)g_skip, (unsigned long long)(uintptr_t)g_ts};
     kk_csm::GraphEntry* ge = nullptr;
     for (auto& g : m->graphs)
       if (g.key == key) ge = &g;
@@ -2139,7 +2278,6 @@ extern "C" int kk_csm_debug_timestamps(unsigned long long* buf, int capacity) {
 
 extern "C" int kk_csm_debug_skip(int mask) {
   g_skip = mask & 0xffff;
-  g_dbg = (mask >> 16) & 15;
   return 0;
 }
 

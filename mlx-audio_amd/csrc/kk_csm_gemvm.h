@@ -55,7 +55,7 @@ struct FGArgs {
   const float* res; long long rrs;  // EPI 1
   float* out; long long ors;
   long long pss;                    // EPI 2: floats between the partial tiles of consecutive K slices
-  int dbg;                          // KK_CSM_DBG (TIMING ONLY, wrong results): 1 no input staging, 2 no FMAs, 4 no reduction, 8 no weight loads
+  int dbg;                          // gemvm_kernel: bit 0 = plain instead of nontemporal weight loads (KK_CSM_NT); the round-2 kernels: KK_CSM_DBG phase switches
   unsigned long long* ts; int ts_id;  // kk_csm_debug_timestamps (null in production)
 };
 
@@ -133,11 +133,20 @@ __global__ __launch_bounds__(512) void gemvm_kernel(FGArgs a) {
     }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_sched_barrier(0);
+  if (a.dbg & 1) {  // matrices that are re-read within the reach of the memory-side cache (the depth decoder: 222 MB, 31 times per frame): plain loads
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = wave + 8 * j, cc = c < nch ? c : nch - 1;
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave + 8 * j, cc = c < nch ? c : nch - 1;
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)(cc * NSUB + s) * 64);
+      for (int s = 0; s < NSUB; ++s) ring[j][s] = *(wblk + (long long)(cc * NSUB + s) * 64);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = wave + 8 * j, cc = c < nch ? c : nch - 1;
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) ring[j][s] = __builtin_nontemporal_load(wblk + (long long)(cc * NSUB + s) * 64);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise issues most of the weight loads BEHIND the split arithmetic to save registers)
   // ---- prologue, exact three-way bf16 split, fragment order

@@ -59,6 +59,14 @@ tp = time.perf_counter()
 codes = model.generate_frame(torch.tensor(tok), torch.tensor(msk), temperature=0.9, top_k=50, uniforms=torch.tensor(rng.uniform(size=(B, n)).astype(np.float32)))
 torch.cuda.synchronize()
 prefill_ms = (time.perf_counter() - tp) * 1e3
+# the same prompt again on reset caches: without the first call's one-time costs (kernel loading, workspace allocation)
+model.reset_caches()
+ptok, pmsk, pu = torch.tensor(tok).cuda(), torch.tensor(msk).cuda(), torch.tensor(rng.uniform(size=(B, n)).astype(np.float32)).cuda()
+torch.cuda.synchronize()
+tp = time.perf_counter()
+codes = model.generate_frame(ptok, pmsk, temperature=0.9, top_k=50, uniforms=pu)
+torch.cuda.synchronize()
+prefill2_ms = (time.perf_counter() - tp) * 1e3
 step_tok = torch.zeros((B, 1, n + 1), dtype=torch.int32, device="cuda")
 step_msk = torch.zeros((B, 1, n + 1), dtype=torch.float32, device="cuda")
 step_msk[:, 0, :n] = 1
@@ -75,6 +83,6 @@ for i in range(a.frames):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - ts) / a.frames
 print(json.dumps({"metric": "audio-sec/sec (xRT), CSM-1B frame generation (80 ms of audio per frame and stream), " + ("bf16 weights / fp32 arithmetic" if a.weights == "bfloat16" else "fp32"), "value": B * 0.08 / dt,
-                  "ms_per_frame": dt * 1e3, "batch": B, "prompt_tokens": a.prompt, "prefill_ms": prefill_ms, "frames_timed": a.frames, "dtype": "bf16 weights, f32 arithmetic" if a.weights == "bfloat16" else "f32",
+                  "ms_per_frame": dt * 1e3, "batch": B, "prompt_tokens": a.prompt, "prefill_ms": prefill_ms, "prefill_ms_second_call": prefill2_ms, "frames_timed": a.frames, "dtype": "bf16 weights, f32 arithmetic" if a.weights == "bfloat16" else "f32",
                   "data": "synthetic (random-init CSM-1B weights, random prompt, injected uniforms)",
                   "setup_s": {"synth_checkpoint": round(t1 - t0, 1), "load_finalize": round(t2 - t1, 1)}}))

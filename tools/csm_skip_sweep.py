@@ -60,7 +60,5 @@ for b, nm in enumerate(names):
 out["only q|k|v + attention"] = round(frame_ms(511 & ~3), 3)
 out["only gate|up + down"] = round(frame_ms(511 & ~24), 3)
 out["only gate|up + down + combine"] = round(frame_ms(511 & ~56), 3)
-for bits, nm in ((1, "no input staging"), (2, "no matrix instructions"), (4, "no reduction"), (8, "no weight loads"), (9, "no staging, no weights"), (15, "all four off")):
-    out[f"gemvm phases: {nm}"] = round(frame_ms(bits << 16), 3)
 model.lib.kk_csm_debug_skip(0)
 print(json.dumps(out, indent=1))
