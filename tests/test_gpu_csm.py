@@ -219,6 +219,44 @@ def test_csm_head_dims_of_the_real_model_on_a_short_stack():
     np.testing.assert_array_equal(got2.cpu().numpy(), ref2)
 
 
+def test_csm_full_width_layers_split_k_and_wide_blocks_match_oracle():
+    """ONE backbone and ONE decoder layer at the real widths (hidden 2048 / 1024, intermediate 8192): the shapes where the matrix-core GEMV takes its
+    other forms -- 64-column blocks (gate|up, N = 16384), 8 split-K slices + combine (down, K = 8192), two straight-line rounds (K = 2048) -- and the
+    prompt block its GEMM, against the fp32 oracle on a bf16 checkpoint: logits within 2e-4 of their range, every code equal, prompt and two
+    single-token frames (one sampled on injected uniforms), B = 3 (a partly filled 8-row slice)."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = P.csm_config()
+    cfg = dict(cfg, text_vocab_size=400, audio_vocab_size=300, audio_num_codebooks=4, max_seq_len=64,
+               backbone=dict(cfg["backbone"], num_layers=1), decoder=dict(cfg["decoder"], num_layers=1))
+    w = _as_bf16_checkpoint(P.csm_synth_checkpoint(cfg, 6))
+    rng = np.random.default_rng(31)
+    B, n = 3, cfg["audio_num_codebooks"]
+    orc = C.CsmOracle(w, cfg)
+    model = SesameModel(cfg, w, weight_dtype="bfloat16")
+    model.setup_caches(B)
+    tok, msk = _prompt(cfg, rng, B, 7, 3)
+    prev = None
+    for step in range(3):
+        if step == 0:
+            t_in, m_in, temp, u = tok, msk, 0.0, None
+        else:
+            t_in = np.zeros((B, 1, n + 1), np.int64)
+            t_in[:, 0, :n] = prev
+            m_in = np.zeros((B, 1, n + 1), np.float32)
+            m_in[:, 0, :n] = 1
+            temp, u = (0.9, rng.uniform(size=(B, n)).astype(np.float32)) if step == 1 else (0.0, None)
+        trace = {}
+        ref = orc.generate_frame(t_in, m_in, temp=temp, top_k=20, uniforms=u, trace=trace)
+        got = model.generate_frame(torch.tensor(t_in), torch.tensor(m_in), temperature=temp, top_k=20, uniforms=None if u is None else torch.tensor(u))
+        torch.cuda.synchronize()
+        e = err_stats(model.debug_logits().cpu().numpy(), np.stack([trace["c0_logits"]] + trace["ci_logits"], 0))
+        report(f"csm/fullwidth/frame{step}/logits", **e)
+        assert e["rel_max"] < 2e-4, (step, e)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+        prev = ref
+
+
 def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
     """Config-4 data flow on tiny models: reference audio -> Mimi.encode -> prompt frames (text ids | audio codes + EOS frame | text
     ids) -> frame loop -> Mimi.decode -> waveform.  The same loop driven by the two CPU oracles gives the same codes."""
