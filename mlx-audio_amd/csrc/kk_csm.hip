@@ -1376,7 +1376,8 @@ struct Packer {
         u &= 0xFFFF0000u;
         memcpy(&dst[e], &u, 4);
       }
-      if (I % 64 == 0) {
+      // the round-2 / round-3a column-block pack (fused_gemv_kernel, gemv8_kernel) is built only for the A/B runs that ask for those kernels
+      if (I % 64 == 0 && (getenv("KK_CSM_NO_MFMA") || getenv("KK_CSM_OLD") || I % 32 != 0)) {
         l.oct = (O >= 8192 || I >= 4096) ? 8 : 1;  // wide (gate|up) and deep (down) matrices: 64 columns per workgroup
         const int CB = 8 * l.oct, nblk = (O + CB - 1) / CB;
         l.boff = m->packb.size();
@@ -1785,7 +1786,8 @@ int stack_forward(Run& r, Stack& st, float* h, int S, int offset, float* out) {
 // h += Wdown(silu(gate) up).  h [B][rows][D] is updated in place; the consumer applies the final norm (a head's prologue).
 bool stack_can_step(const Stack& st) {
   for (const auto& L : st.layers)
-    if (!(L.qkv.wb && L.o.wb && L.gu.wb && L.down.wb)) return false;
+    for (const Lin* w : {&L.qkv, &L.o, &L.gu, &L.down})
+      if (!(w->wm || w->wb)) return false;
   return !st.layers.empty();
 }
 int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
@@ -1881,9 +1883,9 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   }
   const size_t inner = r.used;
   // bf16 weight mode: single-token frames (and every depth-decoder step) run on the fused five-launch layers
-  const bool fast = m->wdt == KK_BF16 && stack_can_step(m->bb) && stack_can_step(m->dec) && m->proj.wb && m->c0_head.wb;
+  const bool fast = m->wdt == KK_BF16 && stack_can_step(m->bb) && stack_can_step(m->dec) && (m->proj.wm || m->proj.wb) && (m->c0_head.wm || m->c0_head.wb);
   bool heads_fast = fast;
-  for (const auto& l : m->audio_head) heads_fast = heads_fast && l.wb;
+  for (const auto& l : m->audio_head) heads_fast = heads_fast && (l.wm || l.wb);
   const float* last_h;   // the backbone's final-normed last position of every item
   long long last_rs;     // its item pitch
   if (fast && heads_fast && S == 1) {
