@@ -77,6 +77,7 @@ struct kk_csm {
   std::vector<Lin> audio_head;
   int max_batch = 0;
   float* dbg_logits = nullptr;  // [n_cb][maxB][V] of the last frame
+  float* proj_table = nullptr;  // bf16 weight mode: projection(audio_embeddings) [n_cb * V][decoder hidden], computed once at finalize (weights: shared by kk_csm_share)
   // graph replay of the single-token frame step (kk_csm_set_graph_mode)
   struct GraphEntry {
     std::vector<unsigned long long> key;
@@ -1790,7 +1791,8 @@ bool stack_can_step(const Stack& st) {
       if (!(w->wm || w->wb)) return false;
   return !st.layers.empty();
 }
-int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
+// `gather` (optional): layer 0 reads its input rows from a table by code instead of from h, and writes them to h (FGArgs codes / cstride / cb / V / emb)
+int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* gather = nullptr) {
   const kk_llama_args& a = st.a;
   const int B = r.B, H = a.num_heads, KV = a.num_kv_heads, hd = a.head_dim, D = a.hidden, I = a.intermediate;
   const int W = (H + 2 * KV) * hd, M = B * rows;
@@ -1808,6 +1810,7 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset) {
     FGArgs g;
     memset(&g, 0, sizeof g);
     g.x = h; g.xrs = D; g.nw = L.n1.p; g.eps = a.rms_eps; g.out = qkv; g.ors = W;
+    if (l == 0 && gather) { g.codes = gather->codes; g.cstride = gather->cstride; g.cb = gather->cb; g.V = gather->V; g.emb = gather->emb; g.gather_out = h; }
     if (!(g_skip & 1)) CS_TRY(launch_gemv(L.qkv, 1, 0, g, M, r.st));
     if (g_skip & 2) {
     } else if (rows == 1 && st.max_pos <= 64 && H / KV <= 8 && !getenv("KK_CSM_OLD_ATTN")) {
@@ -1916,14 +1919,20 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
     for (int i = 1; i < ncb; ++i) {
       r.used = inner;
       // curr = [last_h, embed(0, c0)] for the first step, [embed(i-1, c_{i-1})] afterwards (sesame.py:373-392): gathered by the projection's prologue
-      if (!r.dry) {
+      // later steps (one row per item): the projection of an embedding row is a row of the table built at finalize -- no launch; the decoder's first
+      // kernel gathers it and materialises the residual stream
+      const bool tabled = rows == 1 && m->proj_table && m->dec.layers[0].qkv.wm && !getenv("KK_CSM_NO_PROJ_TABLE");
+      FGArgs gat;
+      memset(&gat, 0, sizeof gat);
+      gat.codes = codes + (i - 1); gat.cstride = ncb; gat.cb = i - 1; gat.V = V; gat.emb = m->proj_table;
+      if (!r.dry && !tabled) {
         FGArgs g;
         memset(&g, 0, sizeof g);
         g.x = last_h; g.xrs = last_rs; g.codes = codes + (i - 1); g.cstride = ncb; g.cb = i - 1; g.V = V; g.rows = rows; g.emb = m->audio_emb.p;
         g.out = pin; g.ors = Dd;
         if (!(g_skip & 256)) CS_TRY(launch_gemv(m->proj, 3, 0, g, B * rows, r.st));
       }
-      CS_TRY(stack_step(r, m->dec, pin, rows, dpos));
+      CS_TRY(stack_step(r, m->dec, pin, rows, dpos, tabled ? &gat : nullptr));
       if (r.used > peak) peak = r.used;
       dpos += rows;
       if (!r.dry) {
@@ -2046,6 +2055,7 @@ extern "C" void kk_csm_destroy(kk_csm* m) {
   if (!m) return;
   if (m->dev && !m->weights_of) (void)hipFree(m->dev);
   if (m->devb && !m->weights_of) (void)hipFree(m->devb);
+  if (m->proj_table && !m->weights_of) (void)hipFree(m->proj_table);
   for (Stack* s : {&m->bb, &m->dec}) {
     if (s->kc) (void)hipFree(s->kc);
     if (s->vc) (void)hipFree(s->vc);
@@ -2121,6 +2131,17 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
       return kk_fail("kk_csm_finalize: upload failed");
   }
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: stream sync failed");
+  resolve(m, m->bb); resolve(m, m->audio_emb); resolve(m, m->proj);
+  if (m->proj.wm && ncb > 1) {
+    // projection(audio_embeddings): every input the depth decoder's later steps can see (sesame.py:373-392: curr_h = projection(embed(c_{i-1})))
+    const size_t rows = (size_t)V * ncb;
+    if (hipMalloc((void**)&m->proj_table, rows * Dd * sizeof(float)) != hipSuccess) return kk_fail("kk_csm_finalize: hipMalloc failed");
+    GPArgs g;
+    memset(&g, 0, sizeof g);
+    g.x = m->audio_emb.p; g.xrs = D; g.w = m->proj.wm; g.K = D; g.N = Dd; g.M = (int)rows; g.nsub = m->proj.nsub; g.out = m->proj_table; g.ors = Dd;
+    hipLaunchKernelGGL(gemmp_kernel, dim3((Dd + 63) / 64, (unsigned)((rows + 127) / 128)), dim3(256), 0, (hipStream_t)stream, g);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: projection table failed");
+  }
   resolve(m, m->bb); resolve(m, m->dec); resolve(m, m->text_emb); resolve(m, m->audio_emb); resolve(m, m->proj); resolve(m, m->c0_head);
   for (auto& l : m->audio_head) resolve(m, l);
   m->host.clear();

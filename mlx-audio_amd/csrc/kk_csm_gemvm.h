@@ -56,6 +56,7 @@ struct FGArgs {
   float* out; long long ors;
   long long pss;                    // EPI 2: floats between the partial tiles of consecutive K slices
   int dbg;                          // gemvm_kernel: bit 0 = plain instead of nontemporal weight loads (KK_CSM_NT); the round-2 kernels: KK_CSM_DBG phase switches
+  float* gather_out;                // PRO 1 with `codes`: row m is emb[(codes[m * cstride] + cb * V)] (K floats, no x); column block 0 also writes the raw rows here (pitch K)
   unsigned long long* ts; int ts_id;  // kk_csm_debug_timestamps (null in production)
 };
 
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(512) void gemvm_kernel(FGArgs a) {
     if (PRO == 3) {  // an item's last row comes from the audio embedding table (sesame.py:373-392), its other rows from x
       const int item = mg / a.rows, rr = mg - item * a.rows;
       row = rr == a.rows - 1 ? a.emb + (long long)(clamp_id(a.codes[(long long)item * a.cstride], a.V) + a.cb * a.V) * K : a.x + (long long)item * a.xrs;
+    } else if (PRO == 1 && a.codes) {  // rows gathered from a table by code (the depth decoder's input from its projected-embedding table)
+      row = a.emb + (long long)(clamp_id(a.codes[(long long)mg * a.cstride], a.V) + a.cb * a.V) * K;
     } else {
       row = a.x + (long long)mg * a.xrs;
     }
@@ -165,6 +168,11 @@ __global__ __launch_bounds__(512) void gemvm_kernel(FGArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) t[e] = t[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-t[e])) * uu[e];
         } else if (PRO == 1) {
+          if (a.gather_out && nb == 0 && o < noct && r < M) {  // the gathered rows ARE the residual stream: materialised once, by column block 0
+            float* go = a.gather_out + (long long)(m0 + r) * K + k_lo + 8 * o;
+            *(float4*)go = g[ps][p][0];
+            *(float4*)(go + 4) = g[ps][p][1];
+          }
           const float ww[8] = {nw[ps][p][0].x, nw[ps][p][0].y, nw[ps][p][0].z, nw[ps][p][0].w, nw[ps][p][1].x, nw[ps][p][1].y, nw[ps][p][1].z, nw[ps][p][1].w};
           const float cnt = o < noct ? live : 0.0f;  // (a clamped duplicate past the end does not count)
 #pragma unroll
