@@ -74,4 +74,4 @@ for i in range(used):
 print(json.dumps({"instrumented_launches": used, "frame_span_us": (int(t[used - 1, 2]) - int(t[0, 1])) / 100.0,
                   "sum_span_us": sum(r["span_us"] for r in rows), "sum_gap_us": sum(r["gap_us"] or 0 for r in rows)}))
 for r in rows[a.first : a.first + a.count]:
-    print(f"{r['i']:5d} {r['kernel']:34s} gap {r['gap_us']:7.2f}  span {r['span_us']:7.2f}  staged {r['staged_us'] if r['staged_us'] is None else round(r['staged_us'], 2)}  wg0 +{r['wg0_start']:.2f}: staged / weights consumed / reduced / end {r['wg0']}")
+    print(f"{r['i']:5d} {r['kernel']:34s} gap {(r['gap_us'] if r['gap_us'] is not None else 0.0):7.2f}  span {r['span_us']:7.2f}  staged {r['staged_us'] if r['staged_us'] is None else round(r['staged_us'], 2)}  wg0 +{r['wg0_start']:.2f}: staged / weights consumed / reduced / end {r['wg0']}")
