@@ -65,7 +65,7 @@ int kk_launch_lstm(const KKLstmArgs& a, int B, int dtype, hipStream_t st) {
 // bf16 mode, H = 256: Wh stays ON CHIP for the whole sequence.  Thread g owns gate row g (256 weights, bf16):
 // the first 192 live in 96 VGPRs (packed pairs), the last 64 in a 144-byte-pitched LDS row (conflict-free b128 reads).
 // h is kept in LDS as 128 packed bf16 pairs that every lane reads as broadcasts; one v_dot2c_f32_bf16 per weight pair.
-// Per step: 128 dot2 + 32 broadcast reads + 8 row reads per lane, two barriers -- no L2 weight traffic at all (the
+// Per step: 2 x 128 dot2 + 32 broadcast reads + 2 x 8 row reads per lane, one barrier -- no L2 weight traffic at all (the
 // generic kernel above re-streams 1 MiB of fp32 Wh per step and direction).
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -77,18 +77,27 @@ __device__ __forceinline__ float dot2(unsigned w, unsigned h, float acc) {
 }
 
 constexpr int LH = 256, LG = 1024, KR = 192, KL = 64, LWLD = 72;  // LDS row pitch in bf16 elements (144 B)
-constexpr int LSTM_LDS = LG * LWLD * 2 + 128 * 4 + LG * 4;
+constexpr int LSTM_LDS = LG * LWLD * 2 + 2 * 128 * 4;
 
-// 512 threads, each owning TWO gate rows (t and t + 512): 2 x 96 weight registers fit the 256-VGPR budget of two waves
-// per SIMD without spilling, and every broadcast read of h feeds two dot products.
+// 512 threads, each owning TWO gate rows: 2 x 96 weight registers fit the 256-VGPR budget of two waves per SIMD without spilling, and
+// every broadcast read of h feeds two dot products.
+// Round 3 (VERDICT next #10): a step was ~4000 cycles for 2048 cycles of dot products -- the rest were the exchange of the 1024 gate
+// values through LDS with its own barrier, a second barrier behind the state update of 256 threads, and precise expf / tanhf.  Now the
+// four gates of hidden unit j live in ONE LANE PAIR (lane 2j: rows i_j, f_j; lane 2j + 1: rows g_j, o_j), so the gates meet in two DPP
+// exchanges instead of LDS + barrier, both lanes carry c_j and h_j, and h goes into a double-buffered packed-bf16 vector: ONE barrier
+// per step.  Activations: sigmoid(x) = rcp(1 + exp(-x)), tanh(x) = 1 - 2 rcp(1 + exp(2x)) on v_exp_f32 / v_rcp_f32 (1e-6 absolute,
+// far inside the bf16 rounding of h that this mode applies every step anyway).
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
 template <typename T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_h256_bf16_kernel(KKLstmArgs a, const bf16_t* whb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
   bf16_t* wl = (bf16_t*)lsm;                              // [1024][72]
-  unsigned* hb = (unsigned*)(lsm + LG * LWLD * 2);        // [128] packed (h[2k], h[2k+1])
-  float* g_s = (float*)(lsm + LG * LWLD * 2 + 128 * 4);   // [1024]
+  unsigned* hb = (unsigned*)(lsm + LG * LWLD * 2);        // [2][128] packed (h[2k], h[2k+1]), double-buffered over the steps
   const int b = blockIdx.x, dir = blockIdx.y, t0 = threadIdx.x;
-  const int g0 = t0, g1 = t0 + 512;
+  const int j = t0 >> 1, odd = t0 & 1;
+  const int g0 = odd ? 2 * LH + j : j, g1 = odd ? 3 * LH + j : LH + j;  // even lane: i_j, f_j; odd lane: g_j, o_j
   const int L = kk_len(a.len, b);
   const bf16_t* wrow0 = whb + ((long long)dir * LG + g0) * LH;
   const bf16_t* wrow1 = whb + ((long long)dir * LG + g1) * LH;
@@ -105,16 +114,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     *(uint4*)(wl + g0 * LWLD + q * 8) = *(const uint4*)(wrow0 + KR + q * 8);
     *(uint4*)(wl + g1 * LWLD + q * 8) = *(const uint4*)(wrow1 + KR + q * 8);
   }
-  if (t0 < 128) hb[t0] = 0u;
+  if (t0 < 256) hb[t0] = 0u;
   const float* xp = a.xproj + (long long)b * a.Lmax * 2 * LG + (long long)dir * LG;
   T* ob = (T*)a.out + (long long)b * a.obs + dir * LH;
   float c = 0.f;
-  const bool tanh1 = t0 < 256;  // row t0 + 512 is a `g` (tanh) row for t0 < 256, an `o` (sigmoid) row otherwise
   const long long tfirst = dir ? L - 1 : 0;
   float xn0 = L > 0 ? xp[tfirst * 2 * LG + g0] : 0.f, xn1 = L > 0 ? xp[tfirst * 2 * LG + g1] : 0.f;
   __syncthreads();
   for (int step = 0; step < L; ++step) {
     const int t = dir ? (L - 1 - step) : step;
+    const unsigned* hc = hb + (step & 1) * 128;
+    unsigned* hnx = hb + ((step + 1) & 1) * 128;
     float acc0 = xn0, acc1 = xn1;
     if (step + 1 < L) {  // prefetch the next step's input projection
       const long long tn = dir ? t - 1 : t + 1;
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int q = 0; q < KR / 8; ++q) {
-      const uint4 hv = *(const uint4*)(hb + 4 * q);
+      const uint4 hv = *(const uint4*)(hc + 4 * q);
       acc0 = dot2(wa[4 * q], hv.x, acc0);     acc1 = dot2(wb[4 * q], hv.x, acc1);
       acc0 = dot2(wa[4 * q + 1], hv.y, acc0); acc1 = dot2(wb[4 * q + 1], hv.y, acc1);
       acc0 = dot2(wa[4 * q + 2], hv.z, acc0); acc1 = dot2(wb[4 * q + 2], hv.z, acc1);
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int q = 0; q < KL / 8; ++q) {
-      const uint4 hv = *(const uint4*)(hb + KR / 2 + 4 * q);
+      const uint4 hv = *(const uint4*)(hc + KR / 2 + 4 * q);
       const uint4 w0 = *(const uint4*)(wl + g0 * LWLD + q * 8);
       const uint4 w1 = *(const uint4*)(wl + g1 * LWLD + q * 8);
       acc0 = dot2(w0.x, hv.x, acc0); acc1 = dot2(w1.x, hv.x, acc1);
@@ -139,20 +149,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       acc0 = dot2(w0.z, hv.z, acc0); acc1 = dot2(w1.z, hv.z, acc1);
       acc0 = dot2(w0.w, hv.w, acc0); acc1 = dot2(w1.w, hv.w, acc1);
     }
-    g_s[g0] = sigmoidf_(acc0);                           // rows 0..511 are i / f
-    g_s[g1] = tanh1 ? tanhf(acc1) : sigmoidf_(acc1);     // rows 512..767 g, 768..1023 o
-    __syncthreads();
-    if (t0 < LH) {  // waves 0..3: whole waves, so the shuffle below is safe
-      const float ig = g_s[t0], fg = g_s[LH + t0], gg = g_s[2 * LH + t0], og = g_s[3 * LH + t0];
-      c = fg * c + ig * gg;
-      const float h = og * tanhf(c);
-      kk_st(ob + (long long)t * a.ldo + t0, h);
-      const float hn = __shfl_down(h, 1);
-      if ((t0 & 1) == 0) {
-        const bf16x2_t p = {(bf16_t)h, (bf16_t)hn};
-        hb[t0 >> 1] = __builtin_bit_cast(unsigned, p);
-      }
+    // even lane: acc0 = i, acc1 = f; odd lane: acc0 = g, acc1 = o.  tanh(x) = 2 sigmoid(2x) - 1: one code path for both lanes
+    const float sc = odd ? 2.0f : 1.0f;
+    float a0 = sigmoid_fast(acc0 * sc);
+    a0 = odd ? 2.0f * a0 - 1.0f : a0;
+    const float a1 = sigmoid_fast(acc1);
+    const float p0 = __shfl_xor(a0, 1), p1 = __shfl_xor(a1, 1);    // the pair's other two gates
+    c = (odd ? p1 : a1) * c + a0 * p0;  // f c + i g (modules.py:179-186); both lanes of the pair carry the unit's state
+    const float h = (odd ? a1 : p1) * tanh_fast(c);
+    const float hn = __shfl_down(h, 2);  // unit j + 1 (lanes = 0 mod 4 pack a pair; their partner lane + 2 is in the same wave)
+    if ((t0 & 3) == 0) {
+      const bf16x2_t p = {(bf16_t)h, (bf16_t)hn};
+      hnx[t0 >> 2] = __builtin_bit_cast(unsigned, p);
     }
+    if (!odd) kk_st(ob + (long long)t * a.ldo + j, h);
     __syncthreads();
   }
   if (t0 < LH)
