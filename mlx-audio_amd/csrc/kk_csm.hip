@@ -1199,9 +1199,9 @@ static size_t fg_lds_bytes() {
 // gemmp_kernel (round 3): the PROMPT block's Linear layers (M = B x S rows, hundreds to thousands) on the matrix cores, from the same bf16
 // fragment pack and with the same exact three-way bf16 split of the fp32 input as gemvm_kernel -- out[M][N] = x[M][K] W (+ res) in
 // fp32 arithmetic on bf16 weights.  Round 2 ran the prompt through the library's generic fp32 conv kernel (64 launches, 37 ms for a
-// 64-token prompt at B = 8).  A workgroup (4 waves) owns 128 rows x 64 columns (four 16-column sub-blocks, whatever the pack's nsub) and
-// walks K in 32-row chunks: the A operands of a chunk (8 row tiles x 3 terms x 1 KiB) are split on the way from global memory into a
-// double-buffered LDS tile while the matrix instructions of the previous chunk run; wave w multiplies row tiles 2w, 2w + 1 with all four
+// 64-token prompt at B = 8).  A workgroup (4 waves) owns 64 rows x 64 columns (four 16-column sub-blocks, whatever the pack's nsub) and
+// walks K in 32-row chunks: the A operands of a chunk (4 row tiles x 3 terms x 1 KiB) are split on the way from global memory into a
+// double-buffered LDS tile while the matrix instructions of the previous chunk run; wave w multiplies row tile w with all four
 // B fragments (16-byte loads, one chunk ahead).  The three terms of a row accumulate into the SAME accumulator (x1 W + x2 W + x3 W), so a
 // row's result depends on nothing but its own input row: the prompt block is batch-invariant.
 struct GPArgs {
@@ -1211,10 +1211,14 @@ struct GPArgs {
   const float* res; long long rrs;
   float* out; long long ors;
 };
+template <int RT>  // row tiles of 16 per workgroup: 4 (64 rows, one tile per wave; 128-row tiles measured level with them and need 74 KB of LDS)
 __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
-  __shared__ __attribute__((aligned(16))) uint4 abuf[2][8 * 3 * 64];  // [buffer][row tile][term][k octet x 16 rows]
+  constexpr int NIT = RT / 4;      // row tiles per wave
+  constexpr int NLD = RT / 2;      // float4 loads per thread and chunk: (16 RT rows) x (8 quads of 4 k) / 256 threads
+  constexpr int KOP = 384, FRAGB = 4 * KOP;  // k-octet pitch in bytes (256 of data: the two k octets a wave's 8-byte writes touch share no bank), fragment bytes
+  __shared__ __attribute__((aligned(16))) unsigned char abuf[2][RT * 3 * FRAGB];  // [buffer][row tile][term][k octet][16 rows][8 bf16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * 128, sb0 = blockIdx.x * 4, nch = a.K >> 5;
+  const int m0 = blockIdx.y * (16 * RT), sb0 = blockIdx.x * 4, nch = a.K >> 5;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   // B fragment of (chunk c, global sub-block sb): block sb / nsub, sub sb % nsub of the pack [block][chunk][sub][lane]
   const int nsbt = (a.N + 15) >> 4;
@@ -1225,27 +1229,30 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
     bp[s] = (const u32x4*)a.w + ((long long)(sb / a.nsub) * nch * a.nsub + sb % a.nsub) * 64 + lane;
   }
   const long long bstep = (long long)a.nsub * 64;  // per chunk
-  // A staging: thread (row tile tid / 64 (+ 4), k octet (tid / 16) % 4, row tid % 16) takes 8 consecutive k of its row
-  const int ar = tid & 15, ako = (tid >> 4) & 3, amt = tid >> 6;
-  const float* arow[2];
+  // A staging: thread (row tid / 8 + 32 it, quad tid % 8) takes 4 consecutive k of its row: the 8 lanes of a row read one whole 128-byte line
+  // (a thread per (row, k octet) read 64 different lines per wave instruction: the first form of this kernel was bound by exactly that)
+  const int aq = tid & 7, ar0 = tid >> 3;
+  const float* arow[NLD];
+  int aoff[NLD];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int row = m0 + (amt + 4 * it) * 16 + ar;
-    arow[it] = a.x + (long long)(row < a.M ? row : a.M - 1) * a.xrs + ako * 8;
+  for (int it = 0; it < NLD; ++it) {
+    const int rl = ar0 + 32 * it, row = m0 + rl;
+    arow[it] = a.x + (long long)(row < a.M ? row : a.M - 1) * a.xrs + aq * 4;
+    aoff[it] = (rl >> 4) * 3 * FRAGB + (aq >> 1) * KOP + (rl & 15) * 16 + (aq & 1) * 8;
   }
-  float4 g[2][2];
+  float4 g[NLD];
   u32x4 b[4], bn[4];
   auto load_a = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { g[it][0] = *(const float4*)(arow[it] + 32 * c); g[it][1] = *(const float4*)(arow[it] + 32 * c + 4); }
+    for (int it = 0; it < NLD; ++it) g[it] = *(const float4*)(arow[it] + 32 * c);
   };
   auto store_a = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const float t[8] = {g[it][0].x, g[it][0].y, g[it][0].z, g[it][0].w, g[it][1].x, g[it][1].y, g[it][1].z, g[it][1].w};
-      unsigned x1[4], x2[4], x3[4];
+    for (int it = 0; it < NLD; ++it) {
+      const float t[4] = {g[it].x, g[it].y, g[it].z, g[it].w};
+      unsigned x1[2], x2[2], x3[2];
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
+      for (int e = 0; e < 4; e += 2) {
         const float a0 = t[e], a1 = t[e + 1];
         const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
         const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
@@ -1253,15 +1260,15 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
         x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
         x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
       }
-      uint4* d = &abuf[buf][((amt + 4 * it) * 3) * 64 + ako * 16 + ar];
-      d[0] = make_uint4(x1[0], x1[1], x1[2], x1[3]);
-      d[64] = make_uint4(x2[0], x2[1], x2[2], x2[3]);
-      d[128] = make_uint4(x3[0], x3[1], x3[2], x3[3]);
+      unsigned char* d = &abuf[buf][aoff[it]];
+      *(uint2*)d = make_uint2(x1[0], x1[1]);
+      *(uint2*)(d + FRAGB) = make_uint2(x2[0], x2[1]);
+      *(uint2*)(d + 2 * FRAGB) = make_uint2(x3[0], x3[1]);
     }
   };
-  kk_f32x4 acc[2][4];
+  kk_f32x4 acc[NIT][4];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < NIT; ++mi)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[mi][s] = kk_f32x4{0.f, 0.f, 0.f, 0.f};
   load_a(0);
@@ -1269,6 +1276,7 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
   for (int s = 0; s < 4; ++s) b[s] = *bp[s];
   store_a(0);
   __syncthreads();
+  const int rdoff = (lane >> 4) * KOP + (lane & 15) * 16;
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
     if (more) {
@@ -1277,10 +1285,10 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
       for (int s = 0; s < 4; ++s) bn[s] = *(bp[s] + (long long)(c + 1) * bstep);
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < NIT; ++mi)
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const kk_bf16x8 af = __builtin_bit_cast(kk_bf16x8, abuf[c & 1][((2 * wave + mi) * 3 + t) * 64 + lane]);
+        const kk_bf16x8 af = *(const kk_bf16x8*)&abuf[c & 1][((NIT * wave + mi) * 3 + t) * FRAGB + rdoff];
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[mi][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(kk_bf16x8, b[s]), acc[mi][s], 0, 0, 0);
       }
@@ -1292,13 +1300,13 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
     __syncthreads();
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < NIT; ++mi)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int n = (sb0 + s) * 16 + (lane & 15);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long long row = m0 + (2 * wave + mi) * 16 + 4 * (lane >> 4) + i;
+        const long long row = m0 + (NIT * wave + mi) * 16 + 4 * (lane >> 4) + i;
         if (row < a.M && n < a.N) {
           float v = acc[mi][s][i];
           if (a.res) v += a.res[row * a.rrs + n];
@@ -1548,7 +1556,7 @@ struct Run {
       memset(&g, 0, sizeof g);
       g.x = x; g.xrs = w.Cin; g.w = w.wm; g.K = w.Cin; g.N = w.Cout; g.M = B * rows; g.nsub = w.nsub;
       g.res = res; g.rrs = w.Cout; g.out = out; g.ors = w.Cout;
-      hipLaunchKernelGGL(gemmp_kernel, dim3((w.Cout + 63) / 64, (g.M + 127) / 128), dim3(256), 0, st, g);
+      hipLaunchKernelGGL(gemmp_kernel<4>, dim3((w.Cout + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
       KK_CHECK_LAUNCH();
       if (xn) {
         hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * rows), dim3(256), 0, st, out, nw, w.Cout, eps, xn);
@@ -2139,7 +2147,7 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
     GPArgs g;
     memset(&g, 0, sizeof g);
     g.x = m->audio_emb.p; g.xrs = D; g.w = m->proj.wm; g.K = D; g.N = Dd; g.M = (int)rows; g.nsub = m->proj.nsub; g.out = m->proj_table; g.ors = Dd;
-    hipLaunchKernelGGL(gemmp_kernel, dim3((Dd + 63) / 64, (unsigned)((rows + 127) / 128)), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemmp_kernel<4>, dim3((Dd + 63) / 64, (unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, g);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: projection table failed");
   }
   resolve(m, m->bb); resolve(m, m->dec); resolve(m, m->text_emb); resolve(m, m->audio_emb); resolve(m, m->proj); resolve(m, m->c0_head);
