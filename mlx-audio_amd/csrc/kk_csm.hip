@@ -419,6 +419,156 @@ static size_t attn_step_lds_bytes(int max_pos, int hd, int G) {
   return ((size_t)max_pos * (hd + 4) + (size_t)((max_pos + 3) & ~3) * hd + (size_t)G * hd + (size_t)G * 64 + 16) * 4;
 }
 
+// attn_decode_kernel (round 3): the single-token attention over a LONG cache (the backbone: up to 2048 positions) in chunks of 8192 / hd keys
+// with an online softmax.  attn_cache_kernel<true> walks the keys in dependent steps (a thread per key, then the values 8 keys at a
+// time, one L2 round trip per step): ~9 us at 70 keys, ~20 us at 315 (config 4's prompts), x 16 layers per frame.  Here, as in
+// attn_step_kernel, a workgroup owns one (item, kv head) and its G query heads; a chunk's K and V rows are requested at once (8 + 8
+// 16-byte loads per thread) one chunk AHEAD of the arithmetic, land in LDS, and scores (4 lanes per (head, key)), the running maximum /
+// sum (a wave per head) and the weighted sum (a thread per output, rescaled per chunk) run out of LDS.  RoPE + cache append fused.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int H, int KV, const int* pos_dev, int offset, float* kc, float* vc, int max_pos,
+                                                           float scale, float* out, const float* rope, const int* pad) {
+  constexpr int HD4 = HD / 4, KP = HD + 4, CH = 8192 / HD;
+  extern __shared__ __attribute__((aligned(16))) float smd[];
+  const int G = H / KV, kvh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* ks = smd;                 // [CH][KP]
+  float* vs = ks + CH * KP;        // [CH][HD]
+  float* qs = vs + CH * HD;        // [G][HD]
+  float* sc = qs + G * HD;         // [G][CH]
+  float* kn = sc + G * CH;         // [HD] the new key (RoPE applied)
+  float* vn = kn + HD;             // [HD]
+  float* mrun = vn + HD;           // [G] running maximum
+  float* lrun = mrun + 8;          // [G] running sum
+  float* alpha = lrun + 8;         // [G] rescale factor of the current chunk
+  if (pos_dev) offset += *pos_dev;
+  const int pd = pad ? pad[b] : 0, nk = offset + 1 - pd;
+  const int W = (H + 2 * KV) * HD;
+  if (nk <= 0) {  // a padding row: no key, the output is defined as zero (nothing reads it)
+    for (int o = tid; o < G * HD; o += 256) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = 0.f;
+    return;
+  }
+  const float* kb = kc + ((long long)b * max_pos + pd) * KV * HD + kvh * HD;
+  const float* vb = vc + ((long long)b * max_pos + pd) * KV * HD + kvh * HD;
+  const int nold = nk - 1;  // cached keys; key nk - 1 is the new one (kn / vn)
+  float4 kr[8], vr[8];
+  // rows j0 .. j0 + CH - 1 of the cache (clamped: rows past nold are read and never used; every load unconditional)
+#define KK_LOAD_CHUNK(J0)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                     \
+    const int idx = tid + 256 * i, j = (J0) + idx / HD4, e = idx % HD4, jc = j < nold ? j : (nold > 0 ? nold - 1 : 0); \
+    kr[i] = *(const float4*)(kb + (long long)jc * KV * HD + 4 * e);                                                   \
+    vr[i] = *(const float4*)(vb + (long long)jc * KV * HD + 4 * e);                                                   \
+  }
+  KK_LOAD_CHUNK(0)
+  {  // the new position: RoPE on q (G heads) and k, v as is; k / v also go to the cache
+    const float* cs = rope + (long long)(offset - pd) * (HD / 2) * 2;
+    const float* q = qkv + (long long)b * W + (long long)kvh * G * HD;
+    const float* kq = qkv + (long long)b * W + (H + kvh) * HD;
+    const float* vq = qkv + (long long)b * W + (H + KV + kvh) * HD;
+    float* kdst = kc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
+    float* vdst = vc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
+    for (int i = tid; i < G * (HD / 2); i += 256) {
+      const int ii = i % (HD / 2);
+      const float2 c = *(const float2*)(cs + 2 * ii), x = *(const float2*)(q + 2 * i);
+      *(float2*)(qs + 2 * i) = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
+    }
+    if (tid < HD / 2) {
+      const float2 c = *(const float2*)(cs + 2 * tid), x = *(const float2*)(kq + 2 * tid);
+      const float2 k2 = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
+      *(float2*)(kn + 2 * tid) = k2;
+      *(float2*)(kdst + 2 * tid) = k2;
+    } else if (tid >= 128 && tid < 128 + HD / 2) {
+      const int t = tid - 128;
+      const float2 v = *(const float2*)(vq + 2 * t);
+      *(float2*)(vn + 2 * t) = v;
+      *(float2*)(vdst + 2 * t) = v;
+    }
+    if (tid < 8) { mrun[tid] = -INFINITY; lrun[tid] = 0.f; }
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // outputs o = tid + 256 i of the G x HD (<= 1024)
+  for (int j0 = 0; j0 < nk; j0 += CH) {
+    const int cn = nk - j0 < CH ? nk - j0 : CH, cn4 = (cn + 3) & ~3;
+    // this chunk's rows into LDS (the loads went out a chunk ago); the new key / value take their slot if it falls into the chunk
+    // (rows past the cached keys get zeros: the new key's slot is filled below -- kn / vn are visible only behind the barrier -- and the rows that pad
+    // the key count to a multiple of 4 meet weight exactly 0; unconditional stores, so the loop unrolls and the rows stay in registers)
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, j = idx / HD4, e = idx % HD4;
+      const bool live = j0 + j < nold;
+      *(float4*)(ks + j * KP + 4 * e) = live ? kr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(vs + j * HD + 4 * e) = live ? vr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (nold >= j0 && nold < j0 + CH) {  // (uniform) the new position lies in this chunk: row nold - j0
+      const int jn = nold - j0;
+      for (int e = tid; e < HD; e += 256) { ks[jn * KP + e] = kn[e]; vs[jn * HD + e] = vn[e]; }
+    }
+    KK_LOAD_CHUNK(j0 + CH)  // the next chunk's loads, behind the LDS stores that freed the registers
+    __syncthreads();
+    for (int p = tid >> 2; p < G * cn; p += 64) {  // (head, key) per 4 lanes
+      const int g = p / cn, j = p - g * cn, qd = tid & 3;
+      const float4* kr4 = (const float4*)(ks + j * KP) + qd * (HD4 / 4);
+      const float4* q4 = (const float4*)(qs + g * HD) + qd * (HD4 / 4);
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD4 / 4; e += 2) {
+        const float4 ka = kr4[e], qa = q4[e], kb2 = kr4[e + 1], qb = q4[e + 1];
+        d0 = __builtin_fmaf(qa.x, ka.x, d0); d0 = __builtin_fmaf(qa.y, ka.y, d0); d0 = __builtin_fmaf(qa.z, ka.z, d0); d0 = __builtin_fmaf(qa.w, ka.w, d0);
+        d1 = __builtin_fmaf(qb.x, kb2.x, d1); d1 = __builtin_fmaf(qb.y, kb2.y, d1); d1 = __builtin_fmaf(qb.z, kb2.z, d1); d1 = __builtin_fmaf(qb.w, kb2.w, d1);
+      }
+      float d = d0 + d1;
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      if (qd == 0) sc[g * CH + j] = d * scale;
+    }
+    __syncthreads();
+    for (int g = wave; g < G; g += 4) {  // running softmax of one head over this chunk (<= 128 keys: two per lane)
+      const float v0 = lane < cn ? sc[g * CH + lane] : -INFINITY, v1 = (CH > 64 && lane + 64 < cn) ? sc[g * CH + lane + 64] : -INFINITY;
+      float mx = fmaxf(v0, v1);
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float mo = mrun[g], mn = fmaxf(mo, mx);
+      const float p0 = lane < cn ? expf(v0 - mn) : 0.f, p1 = (CH > 64 && lane + 64 < cn) ? expf(v1 - mn) : 0.f;
+      float sum = p0 + p1;
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      sc[g * CH + lane] = p0;  // (slots >= cn: exact zeros, the weighted sum runs over the padded count)
+      if (CH > 64) sc[g * CH + lane + 64] = p1;
+      if (lane == 0) {
+        const float al = expf(mo - mn);  // exp(-inf) = 0 on the first chunk
+        alpha[g] = al;
+        mrun[g] = mn;
+        lrun[g] = lrun[g] * al + sum;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = tid + 256 * i;
+      if (o < G * HD) {
+        const int g = o / HD, e = o - g * HD;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = 0; j < cn4; j += 4) {
+          const float4 pw = *(const float4*)(sc + g * CH + j);
+          a0 = __builtin_fmaf(pw.x, vs[j * HD + e], a0);
+          a1 = __builtin_fmaf(pw.y, vs[(j + 1) * HD + e], a1);
+          a2 = __builtin_fmaf(pw.z, vs[(j + 2) * HD + e], a2);
+          a3 = __builtin_fmaf(pw.w, vs[(j + 3) * HD + e], a3);
+        }
+        acc[i] = acc[i] * alpha[g] + ((a0 + a1) + (a2 + a3));
+      }
+    }
+    __syncthreads();  // ks / vs / sc are rewritten by the next chunk
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = tid + 256 * i;
+    if (o < G * HD) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = acc[i] / lrun[o / HD];
+  }
+}
+#undef KK_LOAD_CHUNK
+static size_t attn_decode_lds_bytes(int hd, int G) {
+  const size_t CH = 8192 / hd;
+  return (CH * (hd + 4) + CH * hd + (size_t)G * hd + (size_t)G * CH + 2 * hd + 24) * 4;
+}
+
 // dynamic LDS of attn_cache_kernel: scores (padded to 4) + q + G partial outputs of hd floats (G = 512 / hd) + the new k and v rows
 static size_t attn_lds_bytes(int max_pos, int hd) { return ((size_t)((max_pos + 3) & ~3) + hd + (size_t)(512 / hd) * hd + 2 * hd) * 4; }
 
@@ -1835,6 +1985,21 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* 
       else
         hipLaunchKernelGGL(attn_step_kernel<64>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
                            1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, ts_slot());
+      KK_CHECK_LAUNCH();
+    } else if (rows == 1 && H / KV <= 8 && !getenv("KK_CSM_OLD_ATTN")) {
+      const size_t lds = attn_decode_lds_bytes(hd, H / KV);
+      static KKDevOnce attr;
+      if (attr.first()) {
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_lds_bytes(128, 8));
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_lds_bytes(64, 8));
+        attr.done();
+      }
+      if (hd == 128)
+        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev);
+      else
+        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev);
       KK_CHECK_LAUNCH();
     } else if (rows == 1) {
       hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(1, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, 1, H, KV, hd, st.pos_dev,

@@ -257,6 +257,42 @@ def test_csm_full_width_layers_split_k_and_wide_blocks_match_oracle():
         prev = ref
 
 
+def test_csm_long_cache_single_token_attention_across_chunks():
+    """The backbone's single-token attention over a cache longer than one chunk (attn_decode_kernel: 128 keys per chunk at head_dim 64, online
+    softmax across chunks): a 125-position prompt, then six frames whose key counts run 126 .. 131 -- the new key in the last slot of a chunk, alone
+    in the next chunk, and behind it -- against the fp32 oracle: logits within 2e-4 of their range, every code equal (one frame sampled)."""
+    from mlx_audio_amd.csm import SesameModel
+
+    cfg = dict(P.csm_tiny_config(), max_seq_len=160)
+    w = _as_bf16_checkpoint(P.csm_synth_checkpoint(cfg, 9))
+    rng = np.random.default_rng(41)
+    B, n = 2, cfg["audio_num_codebooks"]
+    orc = C.CsmOracle(w, cfg)
+    model = SesameModel(cfg, w, weight_dtype="bfloat16")
+    model.setup_caches(B)
+    tok, msk = _prompt(cfg, rng, B, 100, 25)
+    prev = None
+    for step in range(7):
+        if step == 0:
+            t_in, m_in, temp, u = tok, msk, 0.0, None
+        else:
+            t_in = np.zeros((B, 1, n + 1), np.int64)
+            t_in[:, 0, :n] = prev
+            m_in = np.zeros((B, 1, n + 1), np.float32)
+            m_in[:, 0, :n] = 1
+            temp, u = (0.9, rng.uniform(size=(B, n)).astype(np.float32)) if step == 3 else (0.0, None)
+        trace = {}
+        ref = orc.generate_frame(t_in, m_in, temp=temp, top_k=10, uniforms=u, trace=trace)
+        got = model.generate_frame(torch.tensor(t_in), torch.tensor(m_in), temperature=temp, top_k=10, uniforms=None if u is None else torch.tensor(u))
+        torch.cuda.synchronize()
+        e = err_stats(model.debug_logits().cpu().numpy(), np.stack([trace["c0_logits"]] + trace["ci_logits"], 0))
+        report(f"csm/longcache/frame{step}/logits", **e)
+        assert e["rel_max"] < 2e-4, (step, e)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+        prev = ref
+    assert model.position == 125 + 6
+
+
 def test_csm_end_to_end_loop_reference_audio_prompt_to_waveform():
     """Config-4 data flow on tiny models: reference audio -> Mimi.encode -> prompt frames (text ids | audio codes + EOS frame | text
     ids) -> frame loop -> Mimi.decode -> waveform.  The same loop driven by the two CPU oracles gives the same codes."""
