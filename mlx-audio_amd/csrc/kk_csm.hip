@@ -1361,12 +1361,13 @@ struct GPArgs {
   const float* res; long long rrs;
   float* out; long long ors;
 };
-template <int RT>  // row tiles of 16 per workgroup: 4 (64 rows, one tile per wave; 128-row tiles measured level with them and need 74 KB of LDS)
+template <int RT, int KC>  // RT row tiles of 16 per workgroup (4: one per wave, 8: two per wave); KC 32-row K chunks per barrier (1 or 2)
 __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
   constexpr int NIT = RT / 4;      // row tiles per wave
   constexpr int NLD = RT / 2;      // float4 loads per thread and chunk: (16 RT rows) x (8 quads of 4 k) / 256 threads
   constexpr int KOP = 384, FRAGB = 4 * KOP;  // k-octet pitch in bytes (256 of data: the two k octets a wave's 8-byte writes touch share no bank), fragment bytes
-  __shared__ __attribute__((aligned(16))) unsigned char abuf[2][RT * 3 * FRAGB];  // [buffer][row tile][term][k octet][16 rows][8 bf16]
+  constexpr int CHB = RT * 3 * FRAGB;        // one chunk's A operands: [row tile][term][k octet][16 rows][8 bf16]
+  extern __shared__ __attribute__((aligned(16))) unsigned char abuf[];  // [2 buffers][KC chunks][CHB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * (16 * RT), sb0 = blockIdx.x * 4, nch = a.K >> 5;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1390,63 +1391,71 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
     arow[it] = a.x + (long long)(row < a.M ? row : a.M - 1) * a.xrs + aq * 4;
     aoff[it] = (rl >> 4) * 3 * FRAGB + (aq >> 1) * KOP + (rl & 15) * 16 + (aq & 1) * 8;
   }
-  float4 g[NLD];
-  u32x4 b[4], bn[4];
-  auto load_a = [&](int c) __attribute__((always_inline)) {
+  float4 g[KC][NLD];
+  u32x4 b[KC][4], bn[KC][4];
+  // (a chunk index past the end is clamped: the loads stay unconditional, the extra operands are never multiplied)
+  auto load_ab = [&](int c0, u32x4 (&bd)[KC][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) g[it] = *(const float4*)(arow[it] + 32 * c);
+    for (int kc = 0; kc < KC; ++kc) {
+      const int c = c0 + kc < nch ? c0 + kc : nch - 1;
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) g[kc][it] = *(const float4*)(arow[it] + 32 * c);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bd[kc][s] = *(bp[s] + (long long)c * bstep);
+    }
   };
   auto store_a = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const float t[4] = {g[it].x, g[it].y, g[it].z, g[it].w};
-      unsigned x1[2], x2[2], x3[2];
+    for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const float a0 = t[e], a1 = t[e + 1];
-        const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
-        const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
-        x1[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
-        x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
-        x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+      for (int it = 0; it < NLD; ++it) {
+        const float t[4] = {g[kc][it].x, g[kc][it].y, g[kc][it].z, g[kc][it].w};
+        unsigned x1[2], x2[2], x3[2];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const float a0 = t[e], a1 = t[e + 1];
+          const float b0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), b1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+          const float c0 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u), c1 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+          x1[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+          x2[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(b0), 0x07060302u);
+          x3[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+        }
+        unsigned char* d = abuf + (buf * KC + kc) * CHB + aoff[it];
+        *(uint2*)d = make_uint2(x1[0], x1[1]);
+        *(uint2*)(d + FRAGB) = make_uint2(x2[0], x2[1]);
+        *(uint2*)(d + 2 * FRAGB) = make_uint2(x3[0], x3[1]);
       }
-      unsigned char* d = &abuf[buf][aoff[it]];
-      *(uint2*)d = make_uint2(x1[0], x1[1]);
-      *(uint2*)(d + FRAGB) = make_uint2(x2[0], x2[1]);
-      *(uint2*)(d + 2 * FRAGB) = make_uint2(x3[0], x3[1]);
-    }
   };
   kk_f32x4 acc[NIT][4];
 #pragma unroll
   for (int mi = 0; mi < NIT; ++mi)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[mi][s] = kk_f32x4{0.f, 0.f, 0.f, 0.f};
-  load_a(0);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) b[s] = *bp[s];
+  load_ab(0, b);
   store_a(0);
   __syncthreads();
   const int rdoff = (lane >> 4) * KOP + (lane & 15) * 16;
-  for (int c = 0; c < nch; ++c) {
-    const bool more = c + 1 < nch;
-    if (more) {
-      load_a(c + 1);
+  int buf = 0;
+  for (int c = 0; c < nch; c += KC, buf ^= 1) {
+    load_ab(c + KC, bn);  // the next step's operands: in flight under this step's matrix instructions
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bn[s] = *(bp[s] + (long long)(c + 1) * bstep);
-    }
+    for (int kc = 0; kc < KC; ++kc) {
+      if (c + kc < nch) {
 #pragma unroll
-    for (int mi = 0; mi < NIT; ++mi)
+        for (int mi = 0; mi < NIT; ++mi)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const kk_bf16x8 af = *(const kk_bf16x8*)&abuf[c & 1][((NIT * wave + mi) * 3 + t) * FRAGB + rdoff];
+          for (int t = 0; t < 3; ++t) {
+            const kk_bf16x8 af = *(const kk_bf16x8*)(abuf + (buf * KC + kc) * CHB + ((NIT * wave + mi) * 3 + t) * FRAGB + rdoff);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[mi][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(kk_bf16x8, b[s]), acc[mi][s], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) acc[mi][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(kk_bf16x8, b[kc][s]), acc[mi][s], 0, 0, 0);
+          }
       }
-    if (more) {
-      store_a((c + 1) & 1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) b[s] = bn[s];
     }
+    store_a(buf ^ 1);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[kc][s] = bn[kc][s];
     __syncthreads();
   }
 #pragma unroll
@@ -1464,6 +1473,32 @@ __global__ __launch_bounds__(256) void gemmp_kernel(GPArgs a) {
         }
       }
     }
+}
+// one launch of the prompt GEMM: KK_CSM_GEMM = "RT,KC" picks the tile for A/B runs
+int launch_gemmp(const GPArgs& g, hipStream_t st) {
+  static int rt = 0, kc = 0;
+  if (!rt) {
+    const char* e = getenv("KK_CSM_GEMM");
+    rt = 4; kc = 2;  // (measured level: prefill of 190 positions 30.7 / 31.1 / 33.9 / 36.3 ms for 4,2 / 4,1 / 8,2 / 8,1 -- the split arithmetic redone per column tile, not the tile shape, is what is left)
+    if (e && e[0] && e[1] == ',' && e[2]) { rt = e[0] == '4' ? 4 : 8; kc = e[2] == '1' ? 1 : 2; }
+  }
+#define GP_GO(RT, KC)                                                                                                                   \
+  do {                                                                                                                                   \
+    const size_t lds = (size_t)2 * KC * RT * 3 * 1536;                                                                                   \
+    static KKDevOnce attr;                                                                                                               \
+    if (attr.first()) {                                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)gemmp_kernel<RT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+      attr.done();                                                                                                                       \
+    }                                                                                                                                    \
+    hipLaunchKernelGGL((gemmp_kernel<RT, KC>), dim3((g.N + 63) / 64, (g.M + 16 * RT - 1) / (16 * RT)), dim3(256), lds, st, g);           \
+  } while (0)
+  if (rt == 4 && kc == 1) GP_GO(4, 1);
+  else if (rt == 4) GP_GO(4, 2);
+  else if (kc == 1) GP_GO(8, 1);
+  else GP_GO(8, 2);
+#undef GP_GO
+  KK_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------- host
@@ -1706,8 +1741,7 @@ struct Run {
       memset(&g, 0, sizeof g);
       g.x = x; g.xrs = w.Cin; g.w = w.wm; g.K = w.Cin; g.N = w.Cout; g.M = B * rows; g.nsub = w.nsub;
       g.res = res; g.rrs = w.Cout; g.out = out; g.ors = w.Cout;
-      hipLaunchKernelGGL(gemmp_kernel<4>, dim3((w.Cout + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
-      KK_CHECK_LAUNCH();
+      { const int rc_ = launch_gemmp(g, st); if (rc_ != 0) return rc_; }
       if (xn) {
         hipLaunchKernelGGL(rmsnorm_kernel, dim3(B * rows), dim3(256), 0, st, out, nw, w.Cout, eps, xn);
         KK_CHECK_LAUNCH();
@@ -2312,8 +2346,7 @@ extern "C" int kk_csm_finalize(kk_csm* m, void* stream) {
     GPArgs g;
     memset(&g, 0, sizeof g);
     g.x = m->audio_emb.p; g.xrs = D; g.w = m->proj.wm; g.K = D; g.N = Dd; g.M = (int)rows; g.nsub = m->proj.nsub; g.out = m->proj_table; g.ors = Dd;
-    hipLaunchKernelGGL(gemmp_kernel<4>, dim3((Dd + 63) / 64, (unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, g);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: projection table failed");
+    if (launch_gemmp(g, (hipStream_t)stream) != 0 || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return kk_fail("kk_csm_finalize: projection table failed");
   }
   resolve(m, m->bb); resolve(m, m->dec); resolve(m, m->text_emb); resolve(m, m->audio_emb); resolve(m, m->proj); resolve(m, m->c0_head);
   for (auto& l : m->audio_head) resolve(m, l);
