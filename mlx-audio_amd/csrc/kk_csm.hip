@@ -113,17 +113,33 @@ unsigned long long* ts_slot() { return (g_ts && g_ts_next < g_ts_cap) ? g_ts + 8
 // h[b][s][:] = sum_j mask[b][s][j] * emb_j(tokens[b][s][j]),  j < n_cb: audio_embeddings[token + j*V], j = n_cb: text_embeddings
 __global__ __launch_bounds__(256) void embed_sum_kernel(const int* tokens, const float* mask, const float* audio, const float* text, int ncb, int V, int TV,
                                                         int D, float* h) {
-  const long long row = blockIdx.x;  // b*S + s
-  const int* tk = tokens + row * (ncb + 1);
-  const float* mk = mask + row * (ncb + 1);
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float acc = 0.f;
-    for (int j = 0; j <= ncb; ++j) {
-      const float* e = j < ncb ? audio + ((long long)clamp_id(tk[j], V) + (long long)j * V) * D : text + (long long)clamp_id(tk[j], TV) * D;
-      acc += e[c] * mk[j];
-    }
-    h[row * D + c] = acc;
+  // grid (row = b * S + s, column block of 256).  The row's ids and masks go to LDS first so that the 33 embedding loads of a column do not wait on 33
+  // dependent id loads (the first form walked them one L2 round trip at a time: 60-130 us for the 8 rows of a single-token frame); the loads of 16
+  // code books are in flight together, the sum stays in code-book order.
+  __shared__ int tk_s[72];
+  __shared__ float mk_s[72];
+  const long long row = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if ((int)threadIdx.x <= ncb) {
+    const int j = threadIdx.x;
+    tk_s[j] = j < ncb ? clamp_id(tokens[row * (ncb + 1) + j], V) + j * V : clamp_id(tokens[row * (ncb + 1) + j], TV);
+    mk_s[j] = mask[row * (ncb + 1) + j];
   }
+  __syncthreads();
+  if (c >= D) return;
+  float acc = 0.f;
+  for (int j0 = 0; j0 <= ncb; j0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = j0 + jj <= ncb ? j0 + jj : ncb;
+      v[jj] = (j < ncb ? audio : text)[(long long)tk_s[j] * D + c];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj)
+      if (j0 + jj <= ncb) acc += v[jj] * mk_s[j0 + jj];
+  }
+  h[row * D + c] = acc;
 }
 
 // rows of audio_embeddings for code book `cb`: out[b][pos][:] = audio[(codes[b] + cb*V)][:]   (out row pitch = rows*D per item)
@@ -2088,7 +2104,8 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
   }
   if (r.oom) return kk_fail("kk_csm_generate_frame: workspace too small");
   if (!r.dry) {
-    hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, c.text_vocab_size, D, h);
+    if (ncb > 71) return kk_fail("kk_csm: more than 71 code books");
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(B * S, (D + 255) / 256), dim3(256), 0, r.st, tokens, mask, m->audio_emb.p, m->text_emb.p, ncb, V, c.text_vocab_size, D, h);
     KK_CHECK_LAUNCH();
   }
   const size_t inner = r.used;
