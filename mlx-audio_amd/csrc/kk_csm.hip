@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(const float* qkv, int H,
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 256 * i;
-    if (idx < nold) {
+    if (idx < nold) {  // (kept under the branch: at the depth decoder's 2-32 keys most of the 8 rounds are skipped by whole waves; clamped unconditional loads measured 3 % slower per frame)
       const int j = idx / HD4, e = idx - j * HD4;
       kr[i] = *(const float4*)(kb + (long long)j * KV * HD + 4 * e);
       vr[i] = *(const float4*)(vb + (long long)j * KV * HD + 4 * e);
