@@ -102,6 +102,12 @@ int rup(int v, int m) { return (v + m - 1) / m * m; }
 // kk_csm_debug_skip (TIMING ONLY, wrong results): kernel classes of the single-token step that are not launched -- bit 0 q|k|v, 1 attention,
 // 2 o, 3 gate|up, 4 down, 5 split-K combine, 6 heads, 7 sampler, 8 projection: the in-situ cost of a class is the frame time it removes
 int g_skip = 0;
+// A/B switches consulted on the launch path (environment, read once): bit 0 KK_CSM_PROMPT_F32, 1 KK_CSM_OLD_ATTN, 2 KK_CSM_NO_PROJ_TABLE
+int ab_switches() {
+  static int v = -1;
+  if (v < 0) v = (getenv("KK_CSM_PROMPT_F32") ? 1 : 0) | (getenv("KK_CSM_OLD_ATTN") ? 2 : 0) | (getenv("KK_CSM_NO_PROJ_TABLE") ? 4 : 0);
+  return v;
+}
 // kk_csm_debug_timestamps: in-kernel wall-clock marks (100 MHz) of the instrumented kernels, 8 words per launch in launch order:
 // [class id, earliest workgroup start, latest workgroup end, workgroup 0 after its input loads, workgroup 0's start / shader clock at start / end / shader
 // clock at end]; null in production
@@ -1750,7 +1756,7 @@ struct Run {
         return 0;
       }
     }
-    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && w.wm && w.nsub && !gated && rows > 2 && !getenv("KK_CSM_PROMPT_F32")) {
+    if (xbs == (long long)rows * w.Cin && obs == (long long)rows * w.Cout && w.wm && w.nsub && !gated && rows > 2 && !(ab_switches() & 1)) {
       // the prompt block in bf16 weight mode: matrix cores (gemmp_kernel); KK_CSM_PROMPT_F32=1 keeps the round-2 generic fp32 kernel (A/B).
       // The choice depends on the rows PER ITEM only, never on B: a stream's bits do not depend on its batch.
       GPArgs g;
@@ -2021,7 +2027,7 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* 
     if (l == 0 && gather) { g.codes = gather->codes; g.cstride = gather->cstride; g.cb = gather->cb; g.V = gather->V; g.emb = gather->emb; g.gather_out = h; }
     if (!(g_skip & 1)) CS_TRY(launch_gemv(L.qkv, 1, 0, g, M, r.st));
     if (g_skip & 2) {
-    } else if (rows == 1 && st.max_pos <= 64 && H / KV <= 8 && !getenv("KK_CSM_OLD_ATTN")) {
+    } else if (rows == 1 && st.max_pos <= 64 && H / KV <= 8 && !(ab_switches() & 2)) {
       const size_t lds = attn_step_lds_bytes(st.max_pos, hd, H / KV);
       static KKDevOnce attr;
       if (attr.first()) {
@@ -2036,7 +2042,7 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* 
         hipLaunchKernelGGL(attn_step_kernel<64>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
                            1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, ts_slot());
       KK_CHECK_LAUNCH();
-    } else if (rows == 1 && H / KV <= 8 && !getenv("KK_CSM_OLD_ATTN")) {
+    } else if (rows == 1 && H / KV <= 8 && !(ab_switches() & 2)) {
       const size_t lds = attn_decode_lds_bytes(hd, H / KV);
       static KKDevOnce attr;
       if (attr.first()) {
@@ -2145,7 +2151,7 @@ int run_frame(Run& r, int S, const int* tokens, const float* mask, float temp, i
       // curr = [last_h, embed(0, c0)] for the first step, [embed(i-1, c_{i-1})] afterwards (sesame.py:373-392): gathered by the projection's prologue
       // later steps (one row per item): the projection of an embedding row is a row of the table built at finalize -- no launch; the decoder's first
       // kernel gathers it and materialises the residual stream
-      const bool tabled = rows == 1 && m->proj_table && m->dec.layers[0].qkv.wm && !getenv("KK_CSM_NO_PROJ_TABLE");
+      const bool tabled = rows == 1 && m->proj_table && m->dec.layers[0].qkv.wm && !(ab_switches() & 4);
       FGArgs gat;
       memset(&gat, 0, sizeof gat);
       gat.codes = codes + (i - 1); gat.cstride = ncb; gat.cb = i - 1; gat.V = V; gat.emb = m->proj_table;
