@@ -169,6 +169,96 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = L; t < a.Lmax; ++t) kk_st(ob + (long long)t * a.ldo + t0, 0.f);
 }
 
+// Round 3, second form (lstm_h256_bf16_rs_kernel): the step above is LDS-bound, not VALU-bound -- per CU and step 8 waves x (32 broadcast reads of h +
+// 16 reads of the weight tails) x 8 cycles = 3072 LDS cycles beside 2528 VALU cycles per SIMD.  Here a lane owns 16 ROWS x 32 K instead of 2 rows x 256 k:
+// lane = (row group rg = tid / 8, k group kg = tid % 8); it reads only ITS 16 packed pairs of h (4 reads instead of 32), multiplies them into 16 partial
+// sums (12 pairs of every row in registers, 4 in LDS at a conflict-free [row][thread] layout), and the eight partial sums of a row meet in a
+// REDUCE-SCATTER over DPP adds (row_half_mirror, then quad_perm xor 2, xor 1: 8 + 4 + 2 exchanges), after which lane kg holds local rows 2 kg, 2 kg + 1.
+// The group's 16 rows are ordered (unit, gate), so those are (i, f) of unit kg / 2 for an even lane and (g, o) for its odd neighbour: the lane-pair state
+// update, the packed double-buffered h and the single barrier per step are the ones of the kernel above.  20 LDS reads per wave and step instead of 48.
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); }
+
+constexpr int RS_LDS = 16 * 512 * 16 + 2 * 128 * 4;
+
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_h256_bf16_rs_kernel(KKLstmArgs a, const bf16_t* whb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  uint4* wl = (uint4*)lsm;                              // [16 local rows][512 threads]: pairs 12..15 of the thread's k group
+  unsigned* hb = (unsigned*)(lsm + 16 * 512 * 16);      // [2][128] packed (h[2k], h[2k+1]), double-buffered over the steps
+  const int b = blockIdx.x, dir = blockIdx.y, t0 = threadIdx.x;
+  const int kg = t0 & 7, rg = t0 >> 3, odd = t0 & 1, j = t0 >> 1;  // j: the hidden unit of this lane pair = 4 rg + kg / 2
+  const int L = kk_len(a.len, b);
+  unsigned w[16][12];
+#pragma unroll
+  for (int lr = 0; lr < 16; ++lr) {  // local row lr = 4 (unit in group) + gate  ->  row gate * 256 + 4 rg + unit of Wh
+    const bf16_t* wrow = whb + ((long long)dir * LG + (lr & 3) * LH + 4 * rg + (lr >> 2)) * LH + kg * 32;
+    const uint4 v0 = *(const uint4*)wrow, v1 = *(const uint4*)(wrow + 8), v2 = *(const uint4*)(wrow + 16);
+    w[lr][0] = v0.x; w[lr][1] = v0.y; w[lr][2] = v0.z; w[lr][3] = v0.w;
+    w[lr][4] = v1.x; w[lr][5] = v1.y; w[lr][6] = v1.z; w[lr][7] = v1.w;
+    w[lr][8] = v2.x; w[lr][9] = v2.y; w[lr][10] = v2.z; w[lr][11] = v2.w;
+    wl[lr * 512 + t0] = *(const uint4*)(wrow + 24);
+  }
+  if (t0 < 256) hb[t0] = 0u;
+  const int g0 = odd ? 2 * LH + j : j, g1 = odd ? 3 * LH + j : LH + j;  // the two gate rows this lane finishes: even lane i_j, f_j; odd lane g_j, o_j
+  const float* xp = a.xproj + (long long)b * a.Lmax * 2 * LG + (long long)dir * LG;
+  T* ob = (T*)a.out + (long long)b * a.obs + dir * LH;
+  float c = 0.f;
+  const long long tfirst = dir ? L - 1 : 0;
+  float xn0 = L > 0 ? xp[tfirst * 2 * LG + g0] : 0.f, xn1 = L > 0 ? xp[tfirst * 2 * LG + g1] : 0.f;
+  const bool b2 = (kg & 4) != 0, b1 = (kg & 2) != 0;
+  __syncthreads();
+  for (int step = 0; step < L; ++step) {
+    const int t = dir ? (L - 1 - step) : step;
+    const unsigned* hc = hb + (step & 1) * 128 + kg * 16;
+    unsigned* hnx = hb + ((step + 1) & 1) * 128;
+    const float x0 = xn0, x1 = xn1;
+    if (step + 1 < L) {  // prefetch the next step's input projection
+      const long long tn = dir ? t - 1 : t + 1;
+      xn0 = xp[tn * 2 * LG + g0];
+      xn1 = xp[tn * 2 * LG + g1];
+    }
+    const uint4 h0 = *(const uint4*)hc, h1 = *(const uint4*)(hc + 4), h2 = *(const uint4*)(hc + 8), h3 = *(const uint4*)(hc + 12);
+    float acc[16];
+#pragma unroll
+    for (int lr = 0; lr < 16; ++lr) {
+      const uint4 wt = wl[lr * 512 + t0];
+      float s = 0.f;
+      s = dot2(w[lr][0], h0.x, s); s = dot2(w[lr][1], h0.y, s); s = dot2(w[lr][2], h0.z, s); s = dot2(w[lr][3], h0.w, s);
+      s = dot2(w[lr][4], h1.x, s); s = dot2(w[lr][5], h1.y, s); s = dot2(w[lr][6], h1.z, s); s = dot2(w[lr][7], h1.w, s);
+      s = dot2(w[lr][8], h2.x, s); s = dot2(w[lr][9], h2.y, s); s = dot2(w[lr][10], h2.z, s); s = dot2(w[lr][11], h2.w, s);
+      s = dot2(wt.x, h3.x, s); s = dot2(wt.y, h3.y, s); s = dot2(wt.z, h3.z, s); s = dot2(wt.w, h3.w, s);
+      acc[lr] = s;
+    }
+    // reduce-scatter over the 8 lanes of the row group: a lane keeps the half of its rows its k-group bit selects and receives that half's partial sums
+    float r8[8], r4[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8[i] = (b2 ? acc[i + 8] : acc[i]) + dpp_half_mirror(b2 ? acc[i] : acc[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = (b1 ? r8[i + 4] : r8[i]) + dpp_xor2(b1 ? r8[i] : r8[i + 4]);
+    const float acc0 = x0 + ((odd ? r4[2] : r4[0]) + dpp_xor1(odd ? r4[0] : r4[2]));
+    const float acc1 = x1 + ((odd ? r4[3] : r4[1]) + dpp_xor1(odd ? r4[1] : r4[3]));
+    // even lane: acc0 = i, acc1 = f; odd lane: acc0 = g, acc1 = o.  tanh(x) = 2 sigmoid(2x) - 1: one code path for both lanes
+    const float sc = odd ? 2.0f : 1.0f;
+    float a0 = sigmoid_fast(acc0 * sc);
+    a0 = odd ? 2.0f * a0 - 1.0f : a0;
+    const float a1 = sigmoid_fast(acc1);
+    const float p0 = dpp_xor1(a0), p1 = dpp_xor1(a1);  // the pair's other two gates
+    c = (odd ? p1 : a1) * c + a0 * p0;  // f c + i g (modules.py:179-186); both lanes of the pair carry the unit's state
+    const float h = (odd ? a1 : p1) * tanh_fast(c);
+    const float hn = dpp_xor2(h);  // unit j + 1 sits two lanes up (lanes = 0 mod 4 pack a pair: their xor-2 partner is lane + 2)
+    if ((t0 & 3) == 0) {
+      const bf16x2_t p = {(bf16_t)h, (bf16_t)hn};
+      hnx[t0 >> 2] = __builtin_bit_cast(unsigned, p);
+    }
+    if (!odd) kk_st(ob + (long long)t * a.ldo + j, h);
+    __syncthreads();
+  }
+  if (t0 < LH)
+    for (int t = L; t < a.Lmax; ++t) kk_st(ob + (long long)t * a.ldo + t0, 0.f);
+}
+
 }  // namespace
 
 int kk_launch_lstm_h256_bf16(const KKLstmArgs& a, const void* whb, int B, int dtype, hipStream_t st) {
@@ -178,10 +268,19 @@ int kk_launch_lstm_h256_bf16(const KKLstmArgs& a, const void* whb, int B, int dt
   if (attr_once.first()) {
     (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
     (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LSTM_LDS);
+    (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_rs_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    (void)hipFuncSetAttribute((const void*)lstm_h256_bf16_rs_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     attr_once.done();
   }
+  static int pair_form = -1;
+  if (pair_form < 0) pair_form = getenv("KK_LSTM_PAIR") ? 1 : 0;  // (A/B: the 2-rows-per-lane form)
   dim3 grid(B, 2);
-  if (dtype == KK_F32)
+  if (!pair_form) {
+    if (dtype == KK_F32)
+      hipLaunchKernelGGL(lstm_h256_bf16_rs_kernel<float>, grid, dim3(512), RS_LDS, st, a, (const bf16_t*)whb);
+    else
+      hipLaunchKernelGGL(lstm_h256_bf16_rs_kernel<bf16_t>, grid, dim3(512), RS_LDS, st, a, (const bf16_t*)whb);
+  } else if (dtype == KK_F32)
     hipLaunchKernelGGL(lstm_h256_bf16_kernel<float>, grid, dim3(512), LSTM_LDS, st, a, (const bf16_t*)whb);
   else
     hipLaunchKernelGGL(lstm_h256_bf16_kernel<bf16_t>, grid, dim3(512), LSTM_LDS, st, a, (const bf16_t*)whb);
