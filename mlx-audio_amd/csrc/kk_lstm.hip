@@ -173,7 +173,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 16 reads of the weight tails) x 8 cycles = 3072 LDS cycles beside 2528 VALU cycles per SIMD.  Here a lane owns 16 ROWS x 32 K instead of 2 rows x 256 k:
 // lane = (row group rg = tid / 8, k group kg = tid % 8); it reads only ITS 16 packed pairs of h (4 reads instead of 32), multiplies them into 16 partial
 // sums (12 pairs of every row in registers, 4 in LDS at a conflict-free [row][thread] layout), and the eight partial sums of a row meet in a
-// REDUCE-SCATTER over DPP adds (row_half_mirror, then quad_perm xor 2, xor 1: 8 + 4 + 2 exchanges), after which lane kg holds local rows 2 kg, 2 kg + 1.
+// REDUCE-SCATTER over DPP adds (row_half_mirror, then quad_perm xor 2, xor 1: 8 + 4 + 2 exchanges; the rows sit in the lane's registers in the order
+// the exchange wants, so no selects), after which lane kg holds local rows 2 kg, 2 kg + 1.
 // The group's 16 rows are ordered (unit, gate), so those are (i, f) of unit kg / 2 for an even lane and (g, o) for its odd neighbour: the lane-pair state
 // update, the packed double-buffered h and the single barrier per step are the ones of the kernel above.  20 LDS reads per wave and step instead of 48.
 __device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)); }
@@ -190,15 +191,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int b = blockIdx.x, dir = blockIdx.y, t0 = threadIdx.x;
   const int kg = t0 & 7, rg = t0 >> 3, odd = t0 & 1, j = t0 >> 1;  // j: the hidden unit of this lane pair = 4 rg + kg / 2
   const int L = kk_len(a.len, b);
+  // Register slot i of lane kg holds local row perm(i) = 2 Lq + i % 2 with Lq = [kg, kg^1, kg^2, kg^3, M, M^1, M^2, M^3][i / 2], M = 7 - kg: the rows a lane
+  // KEEPS at every stage of the reduce-scatter are then always the low half of its current slots and the partner's sent half lines up with them -- the
+  // exchange needs no per-lane selects (28 v_cndmask per step otherwise).
   unsigned w[16][12];
 #pragma unroll
-  for (int lr = 0; lr < 16; ++lr) {  // local row lr = 4 (unit in group) + gate  ->  row gate * 256 + 4 rg + unit of Wh
+  for (int i = 0; i < 16; ++i) {  // local row lr = 4 (unit in group) + gate  ->  row gate * 256 + 4 rg + unit of Wh
+    const int q = i >> 1, base = q < 4 ? kg : 7 - kg, lr = 2 * (base ^ (q & 3)) + (i & 1);
     const bf16_t* wrow = whb + ((long long)dir * LG + (lr & 3) * LH + 4 * rg + (lr >> 2)) * LH + kg * 32;
     const uint4 v0 = *(const uint4*)wrow, v1 = *(const uint4*)(wrow + 8), v2 = *(const uint4*)(wrow + 16);
-    w[lr][0] = v0.x; w[lr][1] = v0.y; w[lr][2] = v0.z; w[lr][3] = v0.w;
-    w[lr][4] = v1.x; w[lr][5] = v1.y; w[lr][6] = v1.z; w[lr][7] = v1.w;
-    w[lr][8] = v2.x; w[lr][9] = v2.y; w[lr][10] = v2.z; w[lr][11] = v2.w;
-    wl[lr * 512 + t0] = *(const uint4*)(wrow + 24);
+    w[i][0] = v0.x; w[i][1] = v0.y; w[i][2] = v0.z; w[i][3] = v0.w;
+    w[i][4] = v1.x; w[i][5] = v1.y; w[i][6] = v1.z; w[i][7] = v1.w;
+    w[i][8] = v2.x; w[i][9] = v2.y; w[i][10] = v2.z; w[i][11] = v2.w;
+    wl[i * 512 + t0] = *(const uint4*)(wrow + 24);
   }
   if (t0 < 256) hb[t0] = 0u;
   const int g0 = odd ? 2 * LH + j : j, g1 = odd ? 3 * LH + j : LH + j;  // the two gate rows this lane finishes: even lane i_j, f_j; odd lane g_j, o_j
@@ -207,7 +212,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float c = 0.f;
   const long long tfirst = dir ? L - 1 : 0;
   float xn0 = L > 0 ? xp[tfirst * 2 * LG + g0] : 0.f, xn1 = L > 0 ? xp[tfirst * 2 * LG + g1] : 0.f;
-  const bool b2 = (kg & 4) != 0, b1 = (kg & 2) != 0;
   __syncthreads();
   for (int step = 0; step < L; ++step) {
     const int t = dir ? (L - 1 - step) : step;
@@ -231,14 +235,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       s = dot2(wt.x, h3.x, s); s = dot2(wt.y, h3.y, s); s = dot2(wt.z, h3.z, s); s = dot2(wt.w, h3.w, s);
       acc[lr] = s;
     }
-    // reduce-scatter over the 8 lanes of the row group: a lane keeps the half of its rows its k-group bit selects and receives that half's partial sums
+    // reduce-scatter over the 8 lanes of the row group: a lane keeps the low half of its slots and adds the partner's high half (slot order: see above)
     float r8[8], r4[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r8[i] = (b2 ? acc[i + 8] : acc[i]) + dpp_half_mirror(b2 ? acc[i] : acc[i + 8]);
+    for (int i = 0; i < 8; ++i) r8[i] = acc[i] + dpp_half_mirror(acc[i + 8]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r4[i] = (b1 ? r8[i + 4] : r8[i]) + dpp_xor2(b1 ? r8[i] : r8[i + 4]);
-    const float acc0 = x0 + ((odd ? r4[2] : r4[0]) + dpp_xor1(odd ? r4[0] : r4[2]));
-    const float acc1 = x1 + ((odd ? r4[3] : r4[1]) + dpp_xor1(odd ? r4[1] : r4[3]));
+    for (int i = 0; i < 4; ++i) r4[i] = r8[i] + dpp_xor2(r8[i + 4]);
+    const float acc0 = x0 + (r4[0] + dpp_xor1(r4[2]));  // rows 2 kg, 2 kg + 1 of the group
+    const float acc1 = x1 + (r4[1] + dpp_xor1(r4[3]));
     // even lane: acc0 = i, acc1 = f; odd lane: acc0 = g, acc1 = o.  tanh(x) = 2 sigmoid(2x) - 1: one code path for both lanes
     const float sc = odd ? 2.0f : 1.0f;
     float a0 = sigmoid_fast(acc0 * sc);
