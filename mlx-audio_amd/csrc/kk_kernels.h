@@ -48,6 +48,27 @@ struct KKMfmaArgs {
   KKLen flat_len;
   float post_slope;  // variants 4 / 5 (bf16 out): LeakyReLU(post_slope) of the final stored value; 0 or 1 = none
 };
+// Streaming matrix-core Linear over token rows (kk_linear_rows.hip): out[b][t][:] = act(x[b][t][:] W + bias), zeros past an utterance's length
+struct KKLinMfmaArgs {
+  const bf16_t* x;   // [items][rows][ldx] bf16; the first K channels of a row are read
+  long long xbs;
+  int ldx;
+  const bf16_t* wl;  // fragment pack [ceil(N / 16)][K / 32][64 lanes][8] (kk_linear_pack_index)
+  const float* bias; // [Nb] or null
+  int Nb;
+  bf16_t* out;       // [items][rows][ldo]
+  long long obs;
+  int ldo;
+  int K, N;          // N: channels written (even; columns >= the layer's real width carry zero weights and zero bias)
+  int rows, items;   // rows per item; flat: the items are dense and form ONE row axis of items * rows rows
+  int flat;
+  KKLen len;         // valid rows per item
+  int act;           // KK_ACT_NONE or KK_ACT_GELU (exact erf)
+};
+inline long long kk_linear_pack_index(int o, int i, int K) {  // weight (output column o, input channel i) of a [N][K] Linear
+  return (((long long)(o >> 4) * (K >> 5) + (i >> 5)) * 64 + ((i & 31) >> 3) * 16 + (o & 15)) * 8 + (i & 7);
+}
+int kk_launch_linear_rows_mfma(const KKLinMfmaArgs& a, hipStream_t st);
 bool kk_mfma_eligible(int Cin, int Cout, int Kw, int mode, int stride, int dil);
 int kk_mfma_tile_rows(int Q);  // 128 or 256 output rows per workgroup for a launch covering Q rows per phase
 int kk_launch_conv_mfma(const KKMfmaArgs& a, int B, int out_dtype, hipStream_t st);

@@ -62,6 +62,8 @@ struct ConvW {  // packed [Kw][Cin][ldw] fp32 + bias
   int CinP = 0, CoutP = 0, Cout8 = 0;
   const bf16_t* wb = nullptr;
   const bf16_t* wf = nullptr;  // the same weights in MFMA fragment order (variant-4 kernel, kk_mfma4_pack_index)
+  size_t wl_off = 0;           // k = 1, Cin % 32 == 0: the weights in the streaming Linear kernel's fragment order (kk_linear_rows.hip), 0 = none
+  const bf16_t* wl = nullptr;
   // MX-fp8 pack (kk_set_quantization, bf16 mode, the reference's quantised layer set only): e4m3 fragments + E8M0 scale bytes
   bool fp8 = false;
   size_t q8_off = 0, s8_off = 0;
@@ -189,6 +191,7 @@ struct kk_context {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_fork[2] = {nullptr, nullptr}, side_join[2] = {nullptr, nullptr};
   bool no_side = false;  // debug bit 8 of kk_debug_force_generic: everything on the caller's stream
+  int linrows_mode = 0;  // debug bits 9 / 10: the streaming Linear kernel never / at every size (default: up to KK_LINROWS_MAX rows in flight)
   struct ProfRec { int cls; double flops; double bytes; };
   std::vector<ProfRec> prof_rec;
 };
@@ -425,6 +428,13 @@ struct Packer {
           dst[((size_t)k * c.CoutP + o) * c.CinP + i] = v;
           dfr[kk_mfma4_pack_index(k, o, i, c.CoutP, c.CinP)] = v;
         }
+    if (K == 1 && I % 32 == 0) {  // Linear layers: the streaming kernel's pack (columns padded to 16 with zeros)
+      const size_t nl = (size_t)kk_cdiv(O, 16) * 16 * I;
+      c.wl_off = alloc((nl + 1) / 2);
+      uint16_t* dl = (uint16_t*)&m->pack[c.wl_off];
+      for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i) dl[kk_linear_pack_index(o, i, I)] = f32_to_bf16_rne(wsrc[(size_t)o * I + i]);
+    }
   }
   // MX-fp8 pack of a Linear weight wsrc[o][i] (the layer set of the reference's quantisation predicate, tts/utils.py:241-260):
   // e4m3 with one power-of-two scale per `q_group` inputs, in MFMA fragment order (kk_mxfp8.hip)
@@ -633,6 +643,7 @@ void resolve(kk_model* m, ConvW& c) {
   c.b = c.has_bias ? m->dev + c.b_off : nullptr;
   c.wb = c.mfma ? (const bf16_t*)(m->dev + c.wb_off) : nullptr;
   c.wf = c.mfma ? (const bf16_t*)(m->dev + c.wf_off) : nullptr;
+  c.wl = (c.mfma && c.wl_off) ? (const bf16_t*)(m->dev + c.wl_off) : nullptr;
   c.q8 = c.fp8 ? (const uint4*)(m->dev + c.q8_off) : nullptr;
   c.s8 = c.fp8 ? (const unsigned char*)(m->dev + c.s8_off) : nullptr;
 }
@@ -971,6 +982,28 @@ struct Ctx {
       int rc = kk_launch_mxfp8_quant_rows(x.p, x.ld, f.M, f.K, q8_aq, q8_as, st);
       if (rc == 0) rc = kk_launch_linear_mxfp8(f, st);
       prof_stop(10, flops, B * (double)Q * (w.Cin * 2.0 + w.Cin * 1.03 * 2.0 + w.Cout * 2.0) + (double)w.Cin * w.Cout * 1.03);
+      return rc;
+    }
+    // Linear layers (k = 1, no fused transform, bias / GELU only): the streaming matrix-core kernel (kk_linear_rows.hip) while few rows are in flight -- the
+    // latency-bound case (B = 1: 37 -> ~10 us per launch); from ~1000 rows on the tiled kernel's operand reuse wins (B = 32: the streaming form costs 4 % of the
+    // step).  Both kernels feed the SAME matrix instruction the same operands in the same K order and share the epilogue arithmetic, so their results are
+    // bit-identical (tests/test_gpu_forward.py::test_streaming_linear_equals_tiled_bitexact) and the choice by size does not touch batch invariance.
+    static int linrows_max = -1;
+    if (linrows_max < 0) { const char* e = getenv("KK_LINROWS_MAX"); linrows_max = e ? atoi(e) : 1024; }
+    const bool lr_size_ok = cx->linrows_mode == 1 || (cx->linrows_mode == 0 && (long long)B * Q <= linrows_max);
+    if (lr_size_ok && w.wl && w.Kw == 1 && can_mfma(w, x, out, o) && out.dtype == KK_BF16 && o.mode == KK_CONV && o.stride == 1 && o.pad == 0 && o.dil == 1 &&
+        o.in_shift == 0 && !o.nrm_a && !o.want_stats && !o.res && !o.accumulate && o.in_slope == 1.f && o.scale == 1.f && o.post_slope == 1.f &&
+        (o.act == KK_ACT_NONE || o.act == KK_ACT_GELU) && Q == x.rows && Q == out.rows && lin.len == lout.len && lin.mul == lout.mul && lin.add == lout.add &&
+        !cx->no_v4) {
+      KKLinMfmaArgs f;
+      memset(&f, 0, sizeof f);
+      f.x = (const bf16_t*)x.p; f.xbs = x.bs; f.ldx = x.ld; f.wl = w.wl; f.bias = w.b; f.Nb = w.CoutP;
+      f.out = (bf16_t*)out.p; f.obs = out.bs; f.ldo = out.ld; f.K = w.Cin; f.N = w.Cout8; f.rows = Q; f.items = B;
+      f.flat = (x.bs == (long long)x.rows * x.ld && out.bs == (long long)out.rows * out.ld) ? 1 : 0;
+      f.len = lout; f.act = o.act;
+      prof_start();
+      const int rc = kk_launch_linear_rows_mfma(f, st);
+      prof_stop(1, flops, bytes);
       return rc;
     }
     if (can_mfma(w, x, out, o)) {
@@ -1990,6 +2023,7 @@ extern "C" void kk_debug_force_generic(kk_context* cx, int on) {
   cx->keep_debug = (on & 16) != 0;      // bit 4: also materialise the tensors that fused kernels skip (conv_post), for kk_debug_fetch
   cx->no_head_fusion = (on & 32) != 0;  // bit 5: stand-alone conv_post + iSTFT head kernels instead of the fused head
   cx->no_side = (on & 256) != 0;        // bit 8: no side stream (every launch of a forward on the caller's stream)
+  cx->linrows_mode = (on & 512) ? 2 : (on & 1024) ? 1 : 0;  // bit 9: Linear layers never on the streaming kernel; bit 10: always (default: by the rows in flight)
   cx->v5_mode = (on & 64) ? 1 : (on & 128) ? 2 : 0;  // bit 6: conv variant 5 (wave-specialised persistent) wherever eligible; bit 7: never (default: >= 9 taps)
 }
 

@@ -440,6 +440,38 @@ def test_result_does_not_depend_on_workspace_contents(dtype, flags, size):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
+def test_streaming_linear_equals_tiled_bitexact():
+    """Linear layers (Albert, bert_encoder, map_in) run on the streaming matrix-core kernel while few rows are in flight (kk_linear_rows.hip: 37 -> ~10 us per
+    launch at B = 1) and on the tiled kernel from ~1000 rows on.  Both feed v_mfma_f32_16x16x32_bf16 the same operands in the same K order and share the
+    epilogue arithmetic: the same bits, so the choice by size cannot break batch invariance.  Production shapes, ragged batch of 3, every text-side stage and
+    the waveform, kernel forced either way (kk_debug_force_generic bits 9 / 10)."""
+    from mlx_audio_amd import _lib
+
+    cfg = P.kokoro_config()
+    w = P.synth_checkpoint(cfg, 0)
+    rng = np.random.default_rng(53)
+    utts = [rng.integers(1, 178, n).tolist() for n in (23, 8, 15)]
+    eng = _engine(cfg, w, "bfloat16")
+    dev = eng.device
+    ref_s = torch.tensor(_style_rows(rng, 3), device=dev)
+    ids, lens, Tmax = eng.pack_ids(utts)
+    sp = torch.ones(3, device=dev)
+    outs = {}
+    for name, flag in (("tiled", 512), ("streaming", 1024)):
+        eng.force(flag)
+        wav, pred, nfr = [t.clone() for t in eng.forward(ids, lens, ref_s, sp, 3 * Tmax, noise_mode=_lib.NOISE_ZERO)]
+        stages = {k: eng.debug_fetch(k).clone() for k in ("bert_dur", "d")}
+        torch.cuda.synchronize()
+        outs[name] = (wav, pred, nfr, stages)
+    eng.force(0)
+    a, b = outs["tiled"], outs["streaming"]
+    for k in ("bert_dur", "d"):
+        assert torch.equal(a[3][k], b[3][k]), k
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[0], b[0])
+    assert bool(torch.isfinite(a[0]).all())
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
 def test_full_config_batch_invariance_bitexact(dtype):
     """The production configuration (Kokoro-82M shapes; bf16 = variant-4 MFMA convs, fused AdaIN / statistics, MFMA attention, on-chip
