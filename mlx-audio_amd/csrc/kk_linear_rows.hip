@@ -2,7 +2,7 @@
 // projections) as a STREAMING matrix-core kernel without LDS and without barriers (round 3, for the B = 1 latency).
 // The tiled convolution kernel runs these at a grid of 6-18 workgroups at B = 1 and walks the 12-32 K slabs of a tile one exposed load latency at a time (one
 // slab of X prefetch, two barriers per slab): 37 us per launch at B = 1 and 46 us at B = 32 -- it does not scale with the work.  Here a WAVE owns 16 rows x 64
-// columns: its A fragment (16 rows x 32 k) is ONE 16-byte global load per lane straight from the row-major activation (lane L: row L % 16, k octet L / 16), its four
+// (or 32) columns: its A fragment (16 rows x 32 k) is ONE 16-byte global load per lane straight from the row-major activation (lane L: row L % 16, k octet L / 16), its four
 // B fragments come from a fragment-order pack of the weight ([N / 16][K / 32][64 lanes][8 bf16]: 1 KiB per wave load), and a register ring keeps PD K chunks in
 // flight.  The rows of a dense [B][T][C] tensor are ONE flat row axis (a tile may span utterances; a row past its utterance's length is stored as zeros).
 // Bias, exact-erf GELU (Albert's ffn), bf16 stores as packed pairs.  A row's result depends on nothing but its own input row: batch-invariant.
@@ -17,8 +17,9 @@ typedef unsigned lr_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lr_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-constexpr int PD = 6;  // K chunks in flight per wave: (1 + 4) x 16-byte registers each
-
+// NS 16-column sub-blocks per wave (the wave owns 16 rows x 16 NS columns), PD K chunks in flight per wave ((1 + NS) 16-byte registers each): NS = 2, PD = 12
+// halves the dependent load rounds of a K = 768 product (2 instead of 4) at twice the waves -- the form for the rows of one or two utterances
+template <int NS, int PD>
 __global__ __launch_bounds__(256) void linear_rows_mfma_kernel(KKLinMfmaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int item = blockIdx.z;  // 0 for the flat form
@@ -28,40 +29,40 @@ __global__ __launch_bounds__(256) void linear_rows_mfma_kernel(KKLinMfmaArgs a) 
   const int nch = a.K >> 5, nsb = (a.N + 15) >> 4;
   const int arow = r0 + (lane & 15) < M ? r0 + (lane & 15) : M - 1;
   const bf16_t* xa = a.x + (long long)item * a.xbs + (long long)arow * a.ldx + 8 * (lane >> 4);
-  const lr_u32x4* bp[4];
+  const lr_u32x4* bp[NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int sb = blockIdx.x * 4 + s < nsb ? blockIdx.x * 4 + s : nsb - 1;  // (a sub-block past the end repeats the last one; not stored)
+  for (int s = 0; s < NS; ++s) {
+    const int sb = blockIdx.x * NS + s < nsb ? blockIdx.x * NS + s : nsb - 1;  // (a sub-block past the end repeats the last one; not stored)
     bp[s] = (const lr_u32x4*)a.wl + ((long long)sb * nch) * 64 + lane;
   }
-  lr_u32x4 ra[PD], rb[PD][4];
+  lr_u32x4 ra[PD], rb[PD][NS];
 #pragma unroll
   for (int p = 0; p < PD; ++p) {
     const int c = p < nch ? p : nch - 1;
     ra[p] = *(const lr_u32x4*)(xa + 32 * c);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) rb[p][s] = bp[s][(long long)c * 64];
+    for (int s = 0; s < NS; ++s) rb[p][s] = bp[s][(long long)c * 64];
   }
-  lr_f32x4 acc[4];
+  lr_f32x4 acc[NS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc[s] = lr_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS; ++s) acc[s] = lr_f32x4{0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < nch; c0 += PD) {
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const int c = c0 + p;
       const lr_bf16x8 av = __builtin_bit_cast(lr_bf16x8, ra[p]);
-      lr_bf16x8 bv[4];
+      lr_bf16x8 bv[NS];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bv[s] = __builtin_bit_cast(lr_bf16x8, rb[p][s]);
+      for (int s = 0; s < NS; ++s) bv[s] = __builtin_bit_cast(lr_bf16x8, rb[p][s]);
       {  // refill the slot (clamped past the end: unconditional loads, exact wait counts)
         const int cn = c + PD < nch ? c + PD : nch - 1;
         ra[p] = *(const lr_u32x4*)(xa + 32 * cn);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) rb[p][s] = bp[s][(long long)cn * 64];
+        for (int s = 0; s < NS; ++s) rb[p][s] = bp[s][(long long)cn * 64];
       }
       if (c < nch) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[s], acc[s], 0, 0, 0);
+        for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[s], acc[s], 0, 0, 0);
       }
     }
   }
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void linear_rows_mfma_kernel(KKLinMfmaArgs a) 
     const int b = a.flat ? row / a.rows : item, t = a.flat ? row - b * a.rows : row;
     const bool live = row < M && t < kk_len(a.len, b < a.items ? b : a.items - 1);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int col = (blockIdx.x * 4 + s) * 16 + (lane & 15);
+    for (int s = 0; s < NS; ++s) {
+      const int col = (blockIdx.x * NS + s) * 16 + (lane & 15);
       float v = acc[s][i] + (a.bias ? a.bias[col < a.Nb ? col : 0] : 0.f);
       if (a.act == KK_ACT_GELU) v = lr_gelu(v);
       if (!live) v = 0.f;
@@ -93,8 +94,15 @@ __global__ __launch_bounds__(256) void linear_rows_mfma_kernel(KKLinMfmaArgs a) 
 int kk_launch_linear_rows_mfma(const KKLinMfmaArgs& a, hipStream_t st) {
   if (a.K % 32 || a.N % 2 || a.rows < 1 || a.items < 1) return kk_fail("linear_rows_mfma: bad shape");
   const int M = a.flat ? a.items * a.rows : a.rows;
-  const dim3 grid((a.N + 63) / 64, (M + 63) / 64, a.flat ? 1 : a.items);
-  hipLaunchKernelGGL(linear_rows_mfma_kernel, grid, dim3(256), 0, st, a);
+  static int wide = -1;
+  if (wide < 0) wide = getenv("KK_LINROWS_WIDE") ? 1 : 0;  // (A/B: 64 columns per wave at every size)
+  if (M <= 256 && !wide) {
+    const dim3 grid((a.N + 31) / 32, (M + 63) / 64, a.flat ? 1 : a.items);
+    hipLaunchKernelGGL((linear_rows_mfma_kernel<2, 12>), grid, dim3(256), 0, st, a);
+  } else {
+    const dim3 grid((a.N + 63) / 64, (M + 63) / 64, a.flat ? 1 : a.items);
+    hipLaunchKernelGGL((linear_rows_mfma_kernel<4, 6>), grid, dim3(256), 0, st, a);
+  }
   KK_CHECK_LAUNCH();
   return 0;
 }
