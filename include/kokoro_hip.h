@@ -165,6 +165,11 @@ int kk_op_layernorm(void* stream, int B, const void* x, int ldx, const void* res
 int kk_op_lstm(void* stream, int B, const float* xproj, const float* whT, int H, int L_rows, const int32_t* len, void* out, int ldo,
                int dtype);
 /* the same recurrence for H = 256 with Wh given as bf16 [2][4H][H] (row = gate row, i|f|g|o) and kept on chip */
+/* The streaming matrix-core Linear of the text side (kk_linear_rows.hip; Albert / bert_encoder / map_in Linears, modules.py:414-512, while few rows are in
+ * flight) on its own: out[b][t][:] = act(x[b][t][:K] W^T + bias) for t < len[b], zeros past it.  x / out bf16 at item pitches xbs / obs elements and row
+ * pitches ldx / ldo; w_bf16 [N][K] row-major bf16; pack_scratch: ceil(N / 16) * 16 * K bf16 of device memory; act 0 none, 2 exact-erf GELU. */
+int kk_op_linear_rows(void* stream, int B, const void* x_bf16, long long xbs, int ldx, int rows, const int32_t* len, const void* w_bf16, int N, int K,
+                      const float* bias, int act, void* pack_scratch, void* out_bf16, long long obs, int ldo);
 int kk_op_lstm_bf16(void* stream, int B, const float* xproj, const void* wh_bf16, int L_rows, const int32_t* len, void* out, int ldo,
                     int dtype);
 /* AlbertSelfAttention core  --  modules.py:497-512 */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "kk_op_layernorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _f, _vp, _i, _i]),
     "kk_op_lstm": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
     "kk_op_lstm_bf16": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i]),
+    "kk_op_linear_rows": (_i, [_vp, _i, _vp, C.c_longlong, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, C.c_longlong, _i]),
     "kk_op_attention": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i]),
     "kk_op_source_stft": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _vp, _i, _i]),
     "kk_op_istft_head": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i]),

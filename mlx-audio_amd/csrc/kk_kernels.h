@@ -65,7 +65,7 @@ struct KKLinMfmaArgs {
   KKLen len;         // valid rows per item
   int act;           // KK_ACT_NONE or KK_ACT_GELU (exact erf)
 };
-inline long long kk_linear_pack_index(int o, int i, int K) {  // weight (output column o, input channel i) of a [N][K] Linear
+__host__ __device__ inline long long kk_linear_pack_index(int o, int i, int K) {  // weight (output column o, input channel i) of a [N][K] Linear
   return (((long long)(o >> 4) * (K >> 5) + (i >> 5)) * 64 + ((i & 31) >> 3) * 16 + (o & 15)) * 8 + (i & 7);
 }
 int kk_launch_linear_rows_mfma(const KKLinMfmaArgs& a, hipStream_t st);

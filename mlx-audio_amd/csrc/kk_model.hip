@@ -1946,6 +1946,31 @@ extern "C" int kk_op_lstm_bf16(void* stream, int B, const float* xproj, const vo
   return kk_launch_lstm_h256_bf16(a, wh_bf16, B, dtype, (hipStream_t)stream);
 }
 
+// the streaming matrix-core Linear on its own (tests): x bf16 [B][rows][ldx] at item pitch xbs elements, w_bf16 [N][K] row-major bf16 (packed into the
+// kernel's fragment order here: `pack_scratch` device memory of ceil(N / 16) * 16 * K bf16), bias fp32 [N] or NULL, out bf16 [B][rows][ldo] at pitch obs
+namespace {
+__global__ void pack_linear_kernel(const bf16_t* w, bf16_t* wl, int N, int K) {
+  const long long n = (long long)((N + 15) / 16 * 16) * K;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int o = (int)(e / K), i = (int)(e - (long long)o * K);
+    wl[kk_linear_pack_index(o, i, K)] = o < N ? w[(long long)o * K + i] : (bf16_t)0.f;
+  }
+}
+}  // namespace
+extern "C" int kk_op_linear_rows(void* stream, int B, const void* x_bf16, long long xbs, int ldx, int rows, const int32_t* len, const void* w_bf16, int N, int K,
+                                 const float* bias, int act, void* pack_scratch, void* out_bf16, long long obs, int ldo) {
+  if (!x_bf16 || !w_bf16 || !pack_scratch || !out_bf16 || B < 1 || rows < 1 || K % 32 || N % 2) return kk_fail("kk_op_linear_rows: bad argument");
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, (bf16_t*)pack_scratch, N, K);
+  KK_CHECK_LAUNCH();
+  KKLinMfmaArgs f;
+  memset(&f, 0, sizeof f);
+  f.x = (const bf16_t*)x_bf16; f.xbs = xbs; f.ldx = ldx; f.wl = (const bf16_t*)pack_scratch; f.bias = bias; f.Nb = N;
+  f.out = (bf16_t*)out_bf16; f.obs = obs; f.ldo = ldo; f.K = K; f.N = N; f.rows = rows; f.items = B;
+  f.flat = (xbs == (long long)rows * ldx && obs == (long long)rows * ldo) ? 1 : 0;
+  f.len = KKLen{len, len ? 1 : 0, len ? 0 : rows}; f.act = act;
+  return kk_launch_linear_rows_mfma(f, (hipStream_t)stream);
+}
+
 extern "C" int kk_op_attention(void* stream, int B, const void* qkv, int ld, int T_rows, const int32_t* len, int heads, void* out, int ldo,
                                int dtype) {
   KKAttnArgs a;

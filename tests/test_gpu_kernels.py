@@ -860,3 +860,41 @@ def test_conv_mfma_transposed_and_fused(lib, mfma4):
         noise = 2.0 ** -9 / math.sqrt(3.0) * np.sqrt((g64 ** 2).sum(0))
         assert np.all(np.abs(pt[bb, :, 0].sum(0) - g64.sum(0)) <= 5 * noise + 5e-2)
         np.testing.assert_allclose(pt[bb, :, 1].sum(0), (g64 ** 2).sum(0), rtol=3e-3)
+
+
+@pytest.mark.parametrize("B,rows,K,N,act,padded", [(1, 130, 768, 2304, 0, False), (3, 37, 128, 768, 0, True), (2, 130, 2048, 768, 2, False), (9, 130, 768, 512, 2, False)])
+def test_linear_rows_streaming_kernel(lib, B, rows, K, N, act, padded):
+    """kk_linear_rows.hip on its own (the text side's plain Linears while few rows are in flight): bf16 x / W, fp32 accumulation, bias, exact-erf GELU,
+    zeros past an utterance's length; the flat form (dense items: one row axis across utterances, all three wave shapes by row count) and the per-item form
+    (item pitch larger than rows * ld), against torch in fp32 on the same bf16 operands (one bf16 rounding of the result)."""
+    from mlx_audio_amd import _lib
+
+    rng = np.random.default_rng(B * 1000 + rows + K + N)
+    ldx, ldo = K + (8 if padded else 0), N + (16 if padded else 0)
+    xbs, obs = rows * ldx + (64 if padded else 0), rows * ldo + (128 if padded else 0)
+    x = torch.zeros((B, xbs), dtype=torch.bfloat16)
+    xv = torch.tensor(rng.standard_normal((B, rows, K)).astype(np.float32)).to(torch.bfloat16)
+    x[:, : rows * ldx].view(B, rows, ldx)[:, :, :K] = xv
+    w = torch.tensor((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(torch.bfloat16)
+    bias = torch.tensor(rng.standard_normal(N).astype(np.float32))
+    lens = torch.tensor(rng.integers(1, rows + 1, B).astype(np.int32))
+    lens[0] = rows
+    xd, wd, bd, ld = x.cuda(), w.cuda(), bias.cuda(), lens.cuda()
+    scratch = torch.empty(((N + 15) // 16 * 16) * K, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((B, obs), 7.0, dtype=torch.bfloat16, device="cuda")
+    rc = lib.kk_op_linear_rows(stream(), B, P(xd), xbs, ldx, rows, P(ld), P(wd), N, K, P(bd), act, P(scratch), P(out), obs, ldo)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    got = out.cpu()[:, : rows * ldo].view(B, rows, ldo)[:, :, :N].float()
+    ref = xv.float() @ w.float().T + bias
+    if act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    for b in range(B):
+        ref[b, int(lens[b]) :] = 0
+    err = (got - ref).abs()
+    tol = 2.0**-8 * ref.abs() + 1e-3  # one bf16 rounding + fp32 summation order
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert bool((got[0, rows - 1] != 0).any())
+    if padded:  # nothing outside the [rows][N] block of an item is written
+        o = out.cpu()
+        assert bool((o[:, rows * ldo :] == 7.0).all()) and bool((o[:, : rows * ldo].view(B, rows, ldo)[:, :, N:] == 7.0).all())
