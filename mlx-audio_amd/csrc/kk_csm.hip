@@ -449,10 +449,10 @@ static size_t attn_step_lds_bytes(int max_pos, int hd, int G) {
 // sum (a wave per head) and the weighted sum (a thread per output, rescaled per chunk) run out of LDS.  RoPE + cache append fused.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int H, int KV, const int* pos_dev, int offset, float* kc, float* vc, int max_pos,
-                                                           float scale, float* out, const float* rope, const int* pad) {
+                                                           float scale, float* out, const float* rope, const int* pad, int nsplit, float* part) {
   constexpr int HD4 = HD / 4, KP = HD + 4, CH = 8192 / HD;
   extern __shared__ __attribute__((aligned(16))) float smd[];
-  const int G = H / KV, kvh = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = H / KV, kvh = blockIdx.x, b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* ks = smd;                 // [CH][KP]
   float* vs = ks + CH * KP;        // [CH][HD]
   float* qs = vs + CH * HD;        // [G][HD]
@@ -465,8 +465,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
   if (pos_dev) offset += *pos_dev;
   const int pd = pad ? pad[b] : 0, nk = offset + 1 - pd;
   const int W = (H + 2 * KV) * HD;
-  if (nk <= 0) {  // a padding row: no key, the output is defined as zero (nothing reads it)
-    for (int o = tid; o < G * HD; o += 256) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = 0.f;
+  // key split (flash decoding): workgroup z of nsplit takes the chunks z, z + nsplit, ...; with nsplit > 1 it leaves an UNNORMALISED partial result
+  // (sum, running maximum, running sum per head) in `part` and attn_merge_kernel combines the splits
+  float* pz = part + (((long long)b * KV + kvh) * nsplit + z) * (long long)G * (HD + 2);
+  if (nk <= 0 || z * CH >= nk) {  // a padding row (no key: the output is defined as zero) or a split without keys
+    if (nsplit == 1) {
+      for (int o = tid; o < G * HD; o += 256) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = 0.f;
+    } else {
+      for (int o = tid; o < G * (HD + 2); o += 256) pz[o] = (o % (HD + 2)) == HD ? -INFINITY : 0.f;
+    }
     return;
   }
   const float* kb = kc + ((long long)b * max_pos + pd) * KV * HD + kvh * HD;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
     kr[i] = *(const float4*)(kb + (long long)jc * KV * HD + 4 * e);                                                   \
     vr[i] = *(const float4*)(vb + (long long)jc * KV * HD + 4 * e);                                                   \
   }
-  KK_LOAD_CHUNK(0)
+  KK_LOAD_CHUNK(z * CH)
   {  // the new position: RoPE on q (G heads) and k, v as is; k / v also go to the cache
     const float* cs = rope + (long long)(offset - pd) * (HD / 2) * 2;
     const float* q = qkv + (long long)b * W + (long long)kvh * G * HD;
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
     const float* vq = qkv + (long long)b * W + (H + KV + kvh) * HD;
     float* kdst = kc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
     float* vdst = vc + ((long long)b * max_pos + offset) * KV * HD + kvh * HD;
+    const bool appender = (nold / CH) % nsplit == z;  // the split that owns the new key's chunk also appends it to the cache
     for (int i = tid; i < G * (HD / 2); i += 256) {
       const int ii = i % (HD / 2);
       const float2 c = *(const float2*)(cs + 2 * ii), x = *(const float2*)(q + 2 * i);
@@ -497,17 +505,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
       const float2 c = *(const float2*)(cs + 2 * tid), x = *(const float2*)(kq + 2 * tid);
       const float2 k2 = make_float2(x.x * c.x - x.y * c.y, x.y * c.x + x.x * c.y);
       *(float2*)(kn + 2 * tid) = k2;
-      *(float2*)(kdst + 2 * tid) = k2;
+      if (appender) *(float2*)(kdst + 2 * tid) = k2;
     } else if (tid >= 128 && tid < 128 + HD / 2) {
       const int t = tid - 128;
       const float2 v = *(const float2*)(vq + 2 * t);
       *(float2*)(vn + 2 * t) = v;
-      *(float2*)(vdst + 2 * t) = v;
+      if (appender) *(float2*)(vdst + 2 * t) = v;
     }
     if (tid < 8) { mrun[tid] = -INFINITY; lrun[tid] = 0.f; }
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // outputs o = tid + 256 i of the G x HD (<= 1024)
-  for (int j0 = 0; j0 < nk; j0 += CH) {
+  for (int j0 = z * CH; j0 < nk; j0 += nsplit * CH) {
     const int cn = nk - j0 < CH ? nk - j0 : CH, cn4 = (cn + 3) & ~3;
     // this chunk's rows into LDS (the loads went out a chunk ago); the new key / value take their slot if it falls into the chunk
     // (rows past the cached keys get zeros: the new key's slot is filled below -- kn / vn are visible only behind the barrier -- and the rows that pad
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
       const int jn = nold - j0;
       for (int e = tid; e < HD; e += 256) { ks[jn * KP + e] = kn[e]; vs[jn * HD + e] = vn[e]; }
     }
-    KK_LOAD_CHUNK(j0 + CH)  // the next chunk's loads, behind the LDS stores that freed the registers
+    KK_LOAD_CHUNK(j0 + nsplit * CH)  // this split's next chunk: its loads go out behind the LDS stores that freed the registers
     __syncthreads();
     for (int p = tid >> 2; p < G * cn; p += 64) {  // (head, key) per 4 lanes
       const int g = p / cn, j = p - g * cn, qd = tid & 3;
@@ -582,8 +590,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* qkv, int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int o = tid + 256 * i;
-    if (o < G * HD) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = acc[i] / lrun[o / HD];
+    if (o < G * HD) {
+      if (nsplit == 1) out[(long long)b * H * HD + (long long)kvh * G * HD + o] = acc[i] / lrun[o / HD];
+      else pz[(o / HD) * (HD + 2) + o % HD] = acc[i];
+    }
   }
+  if (nsplit > 1 && tid < G) { pz[tid * (HD + 2) + HD] = mrun[tid]; pz[tid * (HD + 2) + HD + 1] = lrun[tid]; }
+}
+// out[b][head][:] = sum_z exp(m_z - m) O_z / sum_z exp(m_z - m) l_z over the key splits of attn_decode_kernel (split order; <= 8 splits, all loads at once).
+// part is [b][kv head][split][G][HD + 2]: head = kv head * G + g, the splits of one head sit G (HD + 2) floats apart.
+template <int HD>
+__global__ __launch_bounds__(HD) void attn_merge_kernel(const float* part, int H, int G, int nsplit, float* out) {
+  const int h = blockIdx.x, b = blockIdx.y, e = threadIdx.x;
+  const int kvh = h / G, g = h - kvh * G;
+  const long long zs = (long long)G * (HD + 2);
+  const float* base = part + (((long long)b * (H / G) + kvh) * nsplit) * zs + (long long)g * (HD + 2);
+  float mz[8], lz[8], oz[8];
+#pragma unroll
+  for (int zz = 0; zz < 8; ++zz) {
+    const float* q = base + (long long)(zz < nsplit ? zz : 0) * zs;
+    mz[zz] = zz < nsplit ? q[HD] : -INFINITY;
+    lz[zz] = q[HD + 1];
+    oz[zz] = q[e];
+  }
+  float m = mz[0];
+#pragma unroll
+  for (int zz = 1; zz < 8; ++zz) m = fmaxf(m, mz[zz]);
+  float num = 0.f, den = 0.f;
+#pragma unroll
+  for (int zz = 0; zz < 8; ++zz) {
+    const float w = mz[zz] == -INFINITY ? 0.f : expf(mz[zz] - m);  // an empty or absent split weighs nothing
+    num = __builtin_fmaf(w, oz[zz], num);
+    den = __builtin_fmaf(w, lz[zz], den);
+  }
+  out[((long long)b * H + h) * HD + e] = den > 0.f ? num / den : 0.f;  // (no key at all: zero, as in the unsplit form)
 }
 #undef KK_LOAD_CHUNK
 static size_t attn_decode_lds_bytes(int hd, int G) {
@@ -2014,6 +2054,7 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* 
   float* att = r.f32((size_t)M * H * hd);
   float* gu = r.f32((size_t)M * 2 * I);
   float* part = r.f32((size_t)16 * M * D);  // partial tiles of a split-K down projection (<= 16 slices)
+  float* attp = r.f32((size_t)8 * M * H * (hd + 2));  // key-split partials of the long-cache attention (<= 8 splits)
   if (r.oom) return kk_fail("kk_csm: workspace too small");
   if (r.dry) return 0;
   if (offset + rows > st.max_pos) return kk_fail("kk_csm: sequence exceeds the cache (max_seq_len)");
@@ -2050,12 +2091,22 @@ int stack_step(Run& r, Stack& st, float* h, int rows, int offset, const FGArgs* 
         (void)hipFuncSetAttribute((const void*)attn_decode_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_lds_bytes(64, 8));
         attr.done();
       }
+      // key splits: one per 2 chunks of the longest cache, at most 8 (the backbone's 2048 positions: 8 splits of 2 chunks; short test stacks: 1-2)
+      const int CHk = 8192 / hd, nchunks = (st.max_pos + CHk - 1) / CHk;
+      int nsplit = (nchunks + 1) / 2;
+      nsplit = nsplit < 1 ? 1 : (nsplit > 8 ? 8 : nsplit);
+      if (nsplit > 1 && !attp) return kk_fail("kk_csm: internal: attention partials");
       if (hd == 128)
-        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
-                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev);
+        hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(KV, B, nsplit), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, nsplit, attp);
       else
-        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(KV, B), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
-                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev);
+        hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(KV, B, nsplit), dim3(256), lds, r.st, qkv, H, KV, st.pos_dev, st.pos_dev ? 0 : offset, kc, vc, st.max_pos,
+                           1.0f / sqrtf((float)hd), att, st.rope.p, st.pad_dev, nsplit, attp);
+      KK_CHECK_LAUNCH();
+      if (nsplit > 1) {
+        if (hd == 128) hipLaunchKernelGGL(attn_merge_kernel<128>, dim3(H, B), dim3(128), 0, r.st, attp, H, H / KV, nsplit, att);
+        else hipLaunchKernelGGL(attn_merge_kernel<64>, dim3(H, B), dim3(64), 0, r.st, attp, H, H / KV, nsplit, att);
+      }
       KK_CHECK_LAUNCH();
     } else if (rows == 1) {
       hipLaunchKernelGGL(attn_cache_kernel<true>, dim3(1, H, B), dim3(128), attn_lds_bytes(st.max_pos, hd), r.st, qkv, 1, H, KV, hd, st.pos_dev,

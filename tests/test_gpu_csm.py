@@ -263,7 +263,7 @@ def test_csm_long_cache_single_token_attention_across_chunks():
     in the next chunk, and behind it -- against the fp32 oracle: logits within 2e-4 of their range, every code equal (one frame sampled)."""
     from mlx_audio_amd.csm import SesameModel
 
-    cfg = dict(P.csm_tiny_config(), max_seq_len=160)
+    cfg = dict(P.csm_tiny_config(), max_seq_len=520)  # 5 chunks of 128 keys: three key splits, two of them with keys here
     w = _as_bf16_checkpoint(P.csm_synth_checkpoint(cfg, 9))
     rng = np.random.default_rng(41)
     B, n = 2, cfg["audio_num_codebooks"]
