@@ -386,14 +386,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(KKLnArgs a) {
   const T* rr = a.res ? (const T*)a.res + (long long)b * a.rbs + (long long)row * a.ldr : nullptr;
   constexpr int MAXV = 32;  // C <= 2048
   float v[MAXV];
+  // the scale / shift of the last loop are requested HERE, with the row: they depend on nothing, and read where they are used they are a second
+  // exposed round trip behind the two reductions (the kernel is one wave per row: nothing else hides it)
+  float pg[MAXV], pb[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + 64 * i;
     float t = 0.f;
+    pg[i] = pb[i] = 0.f;
     if (c < a.C) {
       t = kk_ld(xr + c);
       if (rr) t += kk_ld(rr + c);
+      if (a.gb) { pg[i] = a.gb[(long long)b * a.gbs + c]; pb[i] = a.gb[(long long)b * a.gbs + a.C + c]; }
+      else { pg[i] = a.w[c]; pb[i] = a.bias[c]; }
     }
     v[i] = t;
     s += t;
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(KKLnArgs a) {
     const int c = lane + 64 * i;
     if (c < a.C) {
       float y = (v[i] - mean) * rstd;
-      if (a.gb) y = (1.0f + a.gb[(long long)b * a.gbs + c]) * y + a.gb[(long long)b * a.gbs + a.C + c];
-      else y = y * a.w[c] + a.bias[c];
+      if (a.gb) y = (1.0f + pg[i]) * y + pb[i];
+      else y = y * pg[i] + pb[i];
       if (a.act == KK_ACT_LRELU) y = y > 0.f ? y : y * a.slope;
       kk_st(orow + c, y);
     }
