@@ -1653,6 +1653,7 @@ struct Packer {
         while (l.ks > 1 && (I % l.ks != 0 || (I / l.ks) % 32 != 0)) --l.ks;
         const int nb16 = (O + 15) / 16;
         l.nsub = nb16 * l.ks / 4 >= 192 ? 4 : (nb16 * l.ks / 2 >= 192 ? 2 : 1);
+        if (const char* e = getenv("KK_CSM_NSUB_MAX")) { const int mx = atoi(e); if (mx >= 1 && l.nsub > mx) l.nsub = mx; }  // (A/B: narrower column blocks = more workgroups; measured: 2 instead of 4 sub-blocks for gate|up costs +0.09 ms per frame)
         const int CBm = 16 * l.nsub, nblk = (O + CBm - 1) / CBm, nchunk = I / 32;
         l.moff = m->packb.size();
         m->packb.resize(l.moff + (size_t)nblk * I * CBm, 0);
